@@ -1,0 +1,56 @@
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+PKG = "audio-classification-using-a-deep-cnn-combined-with-multi-level-attention_amd"
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return importlib.import_module(PKG)
+
+
+@pytest.fixture(scope="session")
+def W():
+    return importlib.import_module(PKG + ".weights")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+        return cache[name]
+    return load
+
+
+@pytest.fixture(scope="session")
+def mk():
+    """Input generators shared with the fixture generator (no reference import happens
+    at module import time; see tests/golden/make_golden.py)."""
+    return importlib.import_module("make_golden")

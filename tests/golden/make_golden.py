@@ -1,0 +1,323 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz by running the REFERENCE itself (build container only).
+
+Usage (from the repo root, in the container that has /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference is imported from /root/reference with empty stub modules for the
+packages it imports but never calls on this path (resampy, soundfile, torchvision);
+nothing of the reference is copied: the fixtures hold only numeric inputs/outputs.
+Inputs, weights and dropout masks are NOT stored; both sides regenerate them from
+the portable integer-hash RNG in ``<package>/weights.py`` (seeds recorded below).
+``train.py`` of the reference cannot be imported (it imports librosa/h5py at module
+level via dataset.py), so the training step is driven here with the same stock
+PyTorch calls the reference uses (train.py:119-142, :283-303, :369-372) on the
+reference's own ``model.Ensemble``.
+"""
+
+import importlib
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+PKG = "audio-classification-using-a-deep-cnn-combined-with-multi-level-attention_amd"
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ROOT)
+W = importlib.import_module(PKG + ".weights")
+
+
+def import_reference():
+    for name in ("resampy", "soundfile", "torchvision", "torchvision.models"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["torchvision.models"].resnet50 = lambda *a, **k: None
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    sys.path.insert(0, REF)
+    from torchvggish import mel_features, vggish_input, vggish  # noqa: E402
+    import model as ref_model  # noqa: E402
+    return mel_features, vggish_input, vggish, ref_model
+
+
+def test_waveforms():
+    """name -> float64 waveform; regenerated identically by tests/_inputs.py."""
+    sr = 16000
+    t = lambda n: np.arange(n, dtype=np.float64) / sr
+    out = {}
+    out["noise_160000"] = W.uniform(11, W.stream_id("noise_160000"), 160000, dtype=np.float64)
+    out["noise_30960"] = W.uniform(12, W.stream_id("noise_30960"), 30960, dtype=np.float64)
+    out["sine1k_15600"] = 0.5 * np.sin(2 * np.pi * 1000.0 * t(15600))
+    out["silence_16000"] = np.zeros(16000)
+    n = 64000
+    out["chirp_64000"] = 0.8 * np.sin(2 * np.pi * (50.0 * t(n) + 0.5 * (7000.0 / (n / sr)) * t(n) ** 2))
+    out["quiet_noise_47000"] = 1e-3 * W.uniform(13, W.stream_id("quiet_noise_47000"), 47000, dtype=np.float64)
+    st = W.uniform(14, W.stream_id("stereo_20000"), 40000, dtype=np.float64).reshape(20000, 2)
+    out["stereo_20000"] = st
+    return out
+
+
+def gen_frontend(mel_features, vggish_input):
+    g = {}
+    g["hann400"] = mel_features.periodic_hann(400)
+    m = mel_features.spectrogram_to_mel_matrix(num_mel_bins=64, num_spectrogram_bins=257,
+                                               audio_sample_rate=16000, lower_edge_hertz=125,
+                                               upper_edge_hertz=7500)
+    r, c = np.nonzero(m)
+    g["mel_rows"], g["mel_cols"], g["mel_vals"] = r.astype(np.int32), c.astype(np.int32), m[r, c]
+    g["mel_sum"] = np.array(m.sum())
+    m20 = mel_features.spectrogram_to_mel_matrix()
+    g["mel_default_20x129"] = m20
+    g["hz2mel"] = mel_features.hertz_to_mel(np.array([125.0, 7500.0, 1000.0]))
+    for name, wav in test_waveforms().items():
+        ex = vggish_input.waveform_to_examples(wav, 16000, return_tensor=False)
+        g["ex64/" + name] = ex if ex.shape[0] <= 2 else ex[:2]
+        g["ex32/" + name] = ex.astype(np.float32)
+        t = vggish_input.waveform_to_examples(wav, 16000, return_tensor=True)
+        assert tuple(t.shape) == (ex.shape[0], 1, 96, 64) and t.dtype == torch.float32
+        g["tensor_shape/" + name] = np.array(t.shape)
+        g["tensor_requires_grad/" + name] = np.array(int(t.requires_grad))
+    noise = test_waveforms()["noise_30960"]
+    spec = mel_features.stft_magnitude(noise, fft_length=512, hop_length=160, window_length=400)
+    g["stft_rows/noise_30960"] = spec[[0, 1, 95, 96, 190]]
+    g["stft_shape/noise_30960"] = np.array(spec.shape)
+    lm = mel_features.log_mel_spectrogram(noise, audio_sample_rate=16000, log_offset=0.01,
+                                          window_length_secs=0.025, hop_length_secs=0.010,
+                                          num_mel_bins=64, lower_edge_hertz=125, upper_edge_hertz=7500)
+    g["logmel_tail/noise_30960"] = lm[-3:]
+    g["logmel_shape/noise_30960"] = np.array(lm.shape)
+    # generic (non-VGGish) configuration of the same API: 8 kHz defaults
+    x8 = W.uniform(15, W.stream_id("noise8k_4000"), 4000, dtype=np.float64)
+    g["logmel_default8k/noise8k_4000"] = mel_features.log_mel_spectrogram(x8)
+    # sample-count -> (stft frames, examples) table and short-input behaviour
+    counts = [239, 240, 399, 400, 559, 560, 15599, 15600, 15759, 15760, 30959, 30960, 64000, 160000]
+    rows = []
+    for n in counts:
+        try:
+            e = vggish_input.waveform_to_examples(np.zeros(n), 16000, return_tensor=False)
+            rows.append((n, e.shape[0], 0))
+        except ValueError:
+            rows.append((n, -1, 1))
+    g["count_table"] = np.array(rows, dtype=np.int64)
+    return g
+
+
+def load_ref_state(module, sd_np):
+    sd = {k: torch.as_tensor(v) for k, v in sd_np.items()}
+    missing = module.load_state_dict(sd, strict=True)
+    return missing
+
+
+def checksum(t):
+    a = t.detach().double().reshape(-1)
+    idx = (np.arange(16) * 2654435761 % a.numel()).astype(np.int64)
+    return np.concatenate([[a.sum().item(), (a * a).sum().item()], a[idx].numpy()])
+
+
+def gen_vggish(vggish_mod, vggish_input):
+    g = {}
+    torch.manual_seed(0)
+    net = vggish_mod.VGGish(urls={}, pretrained=False, preprocess=False, postprocess=False)
+    net.eval()
+    sd = W.make_state_dict(1, W.vggish_shapes())
+    load_ref_state(net, sd)
+    wav = test_waveforms()["noise_30960"]
+    x = vggish_input.waveform_to_examples(wav, 16000, return_tensor=True).detach()
+    with torch.no_grad():
+        h = x
+        li = 0
+        for layer in net.features:
+            h = layer(h)
+            if isinstance(layer, (torch.nn.ReLU, torch.nn.MaxPool2d)):
+                pass
+            if isinstance(layer, torch.nn.MaxPool2d) or (isinstance(layer, torch.nn.ReLU)):
+                g["feat_checksum/%d" % li] = checksum(h)
+                li += 1
+        g["features_out_shape"] = np.array(h.shape)
+        bott = h.transpose(1, 3).transpose(1, 2).contiguous().view(h.size(0), -1)
+        g["bottleneck"] = bott.numpy()
+        g["embedding"] = net(x).numpy()
+        # preprocess=True path: ndarray + fs -> same embedding
+        net2 = vggish_mod.VGGish(urls={}, pretrained=False, preprocess=True, postprocess=False)
+        net2.eval()
+        load_ref_state(net2, sd)
+        g["embedding_from_wave"] = net2(wav, 16000).numpy()
+        # postprocessor with synthetic PCA parameters (the real ones need a network fetch)
+        pp = vggish_mod.Postprocessor()
+        ev = W.uniform(2, W.stream_id("pca_eigen_vectors"), 128 * 128).reshape(128, 128) * 0.5
+        mu = W.uniform(2, W.stream_id("pca_means"), 128).reshape(128, 1) * 0.5
+        pp.load_state_dict({"pca_eigen_vectors": torch.as_tensor(ev), "pca_means": torch.as_tensor(mu)})
+        g["postprocessed"] = pp(net(x)).numpy()
+    return g
+
+
+class InjectedDropout(torch.nn.Module):
+    """Stands in for nn.Dropout(p) on a reference instance so that both sides use the
+    same keep-mask (instance surgery at run time; the reference's files are untouched)."""
+
+    def __init__(self, p):
+        super().__init__()
+        self.p, self.mask = p, None
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        return x * self.mask.to(x.dtype).reshape(x.shape) / (1.0 - self.p)
+
+
+def install_masks(mla, masks, prefix="mla."):
+    for lvl, em in enumerate(mla.embedded_mappings):
+        for j in range(len(em.dropouts)):
+            if not isinstance(em.dropouts[j], InjectedDropout):
+                em.dropouts[j] = InjectedDropout(0.4)
+            em.dropouts[j].mask = masks["%sembedded_mappings.%d.dropouts.%d" % (prefix, lvl, j)]
+
+
+def make_masks(seed, model_conf, batch, prefix="mla."):
+    out = {}
+    for lvl, n_fc in enumerate(model_conf):
+        for j in range(n_fc):
+            key = "%sembedded_mappings.%d.dropouts.%d" % (prefix, lvl, j)
+            out[key] = torch.as_tensor(W.keep_mask(seed, W.stream_id(key), batch * 10 * 600, 0.4)).reshape(batch, 10, 600)
+    return out
+
+
+def buffers_of(module, prefix=""):
+    return {prefix + k: v.detach().clone().numpy() for k, v in module.state_dict().items()
+            if k.endswith("running_mean") or k.endswith("running_var")}
+
+
+def gen_mla(ref_model):
+    g = {}
+    for tag, emb in (("m128", 128), ("m12288", 12288)):
+        for conf in ([2, 1], [1], [1, 1, 2]):
+            if emb == 12288 and conf != [2, 1]:
+                continue
+            ctag = "%s/c%s" % (tag, "".join(map(str, conf)))
+            mla = ref_model.MultiLevelAttention(conf, emb)
+            sd = W.make_state_dict(3, W.mla_shapes(conf, emb, prefix=""))
+            load_ref_state(mla, sd)
+            B = 4
+            x = torch.as_tensor(W.uniform(4, W.stream_id("mla_in/" + tag), B * 10 * emb, lo=0.0, hi=2.0)).reshape(B, 10, emb)
+            mla.eval()
+            with torch.no_grad():
+                g[ctag + "/eval"] = mla(x).numpy()
+            mla.train()
+            masks = make_masks(5, conf, B, prefix="")
+            install_masks(mla, masks, prefix="")
+            with torch.no_grad():
+                g[ctag + "/train"] = mla(x).numpy()
+            for k, v in buffers_of(mla).items():
+                g[ctag + "/buf/" + k] = v
+    return g
+
+
+CNN_CONF = dict(cnn_type="vggish", num_classes=10, use_pretrained=False, just_bottlenecks=False,
+                cnn_trainable=False, first_cnn_layer_trainable=False, in_channels=1)
+
+
+def synth_bags(seed, batch):
+    """(B, 10, 1, 96, 64) inputs in the value range the front-end produces on noise."""
+    x = W.uniform(seed, W.stream_id("bags"), batch * 10 * 96 * 64, lo=-1.4, hi=4.6)
+    y = W.bits24(seed, W.stream_id("labels"), batch) % 10
+    return torch.as_tensor(x).reshape(batch, 10, 1, 96, 64), torch.as_tensor(y).long()
+
+
+def gen_ensemble(ref_model, vggish_input):
+    g = {}
+    dev = torch.device("cpu")
+    for jb in (False, True):
+        conf = dict(CNN_CONF, just_bottlenecks=jb)
+        ens = ref_model.Ensemble("repeat", conf, [2, 1], dev)
+        sd = W.make_state_dict(6, W.ensemble_shapes((2, 1), jb))
+        load_ref_state(ens, sd)
+        assert list(ens.state_dict().keys()) == list(sd.keys()) or set(ens.state_dict().keys()) == set(sd.keys())
+        ens.eval()
+        waves = W.waveform(21, 160000, 2, dtype=np.float64)
+        ex = torch.cat([vggish_input.waveform_to_examples(w, 16000, return_tensor=True).detach() for w in waves])
+        x = ex.reshape(2, 10, 1, 96, 64)
+        with torch.no_grad():
+            g["wave2logits/jb%d" % jb] = ens(x).numpy()
+        g["n_params/jb%d" % jb] = np.array(sum(p.numel() for p in ens.parameters()))
+        g["n_trainable/jb%d" % jb] = np.array(sum(p.numel() for p in ens.parameters() if p.requires_grad))
+    return g
+
+
+def gen_train(ref_model):
+    """train.py:119-142 semantics on the reference Ensemble: frozen CNN (default) and finetune."""
+    g = {}
+    dev = torch.device("cpu")
+    for tag, finetune, steps, B in (("frozen", False, 10, 8), ("finetune", True, 4, 4)):
+        ens = ref_model.Ensemble("repeat", dict(CNN_CONF), [2, 1], dev)
+        load_ref_state(ens, W.make_state_dict(7, W.ensemble_shapes((2, 1), False)))
+        if finetune:
+            ref_model.set_requires_grad(ens, True)            # train.py:96-97
+        params = [p for p in ens.parameters() if p.requires_grad]   # train.py:283-303
+        opt = torch.optim.Adam(params, lr=0.001)               # train.py:369
+        crit = torch.nn.CrossEntropyLoss()                     # train.py:372
+        ens.train()
+        losses, outs = [], []
+        for s in range(steps):
+            x, y = synth_bags(100 + s, B)
+            install_masks(ens.mla, make_masks(200 + s, [2, 1], B))
+            opt.zero_grad()
+            out = ens(x)
+            loss = crit(out, y)
+            loss.backward()
+            if s == 0:
+                for name, p in ens.named_parameters():
+                    if p.requires_grad:
+                        gn = -1.0 if p.grad is None else float(p.grad.double().norm())
+                        g["%s/gradnorm0/%s" % (tag, name)] = np.array(gn)
+                g["%s/grad0/mla.fc.weight" % tag] = ens.mla.fc.weight.grad.numpy().copy()
+                g["%s/grad0/mla.embedded_mappings.0.norm0.weight" % tag] = ens.mla.embedded_mappings[0].norm0.weight.grad.numpy().copy()
+                g["%s/grad0/mla.attention_modules.1.fcv.weight" % tag] = ens.mla.attention_modules[1].fcv.weight.grad.numpy().copy()
+            opt.step()
+            losses.append(loss.item())
+            outs.append(out.detach().numpy().copy())
+        g[tag + "/losses"] = np.array(losses, dtype=np.float64)
+        g[tag + "/out_first"] = outs[0]
+        g[tag + "/out_last"] = outs[-1]
+        fin = ens.state_dict()
+        for k in ("mla.fc.weight", "mla.fc.bias", "mla.norm.running_mean", "mla.norm.running_var",
+                  "mla.embedded_mappings.0.norm0.running_var", "mla.attention_modules.0.fcv.bias",
+                  "mla.attention_modules.0.fcf.bias", "mla.embedded_mappings.1.fc.0.bias",
+                  "cnn.cnn_model.embeddings.4.bias", "cnn.cnn_model.features.0.bias"):
+            g["%s/final/%s" % (tag, k)] = fin[k].numpy().copy()
+        # eval-mode logits after training (running statistics in use)
+        ens.eval()
+        with torch.no_grad():
+            g[tag + "/eval_after"] = ens(synth_bags(999, 4)[0]).numpy()
+    return g
+
+
+def save(name, g):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **g)
+    print("%-22s %4d arrays %8.1f KB" % (name, len(g), os.path.getsize(path) / 1024.0))
+
+
+def main():
+    torch.set_num_threads(os.cpu_count() or 1)
+    mel_features, vggish_input, vggish_mod, ref_model = import_reference()
+    which = set(sys.argv[1:]) or {"frontend", "vggish", "mla", "ensemble", "train"}
+    if "frontend" in which:
+        save("frontend.npz", gen_frontend(mel_features, vggish_input))
+    if "vggish" in which:
+        save("model_vggish.npz", gen_vggish(vggish_mod, vggish_input))
+    if "mla" in which:
+        save("model_mla.npz", gen_mla(ref_model))
+    if "ensemble" in which:
+        save("model_ensemble.npz", gen_ensemble(ref_model, vggish_input))
+    if "train" in which:
+        save("train.npz", gen_train(ref_model))
+    assert not os.path.exists(os.path.join(REF, "__pycache__")), "bytecode leaked into the reference tree"
+
+
+if __name__ == "__main__":
+    main()
