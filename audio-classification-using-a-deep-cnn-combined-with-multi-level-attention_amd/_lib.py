@@ -1,0 +1,60 @@
+"""ctypes binding of libmla_hip.so (C ABI: include/mla_hip.h).
+
+The library is loaded on first use and NEVER substituted: if it is missing or a call
+fails, the product path raises -- there is no CPU / PyTorch fallback behind it.
+"""
+
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmla_hip.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "mla_hip.h")
+
+F32, BF16, I16 = 0, 1, 2
+E_SHORT = -3
+
+_lib = None
+
+
+class MlaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libmla_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def declared_symbols():
+    """Function names declared in include/mla_hip.h."""
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mla_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "%s is missing: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+                "There is no fallback path." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.mla_last_error.restype = ctypes.c_char_p
+        L.mla_logmel_table_floats.restype = ctypes.c_int64
+        i64, vp, ci = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
+        L.mla_logmel_counts.argtypes = [i64, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+        L.mla_logmel_build_tables.argtypes = [vp]
+        L.mla_logmel_reference_tables.argtypes = [vp, vp]
+        L.mla_logmel_examples.argtypes = [vp, ci, i64, i64, i64, vp, vp, ci, vp]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise MlaError(rc, lib().mla_last_error().decode("utf-8", "replace"))
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,218 @@
+// logmel_core.h -- per-lane arithmetic of the fused log-mel kernel, written so that the
+// SAME source runs (a) inside logmel.hip on gfx950 and (b) on the host, lane by lane,
+// in csrc/logmel_hostsim.cpp (built with g++ by the CPU tests). The host simulation
+// proves the index arithmetic (radix-16 x radix-16 FFT, real-FFT split, sparse mel) against
+// the oracle without a GPU; the GPU parity tests then only have to catch execution-model
+// bugs (barriers, LDS aliasing).
+//
+// Algorithm for ONE STFT frame, executed by a group of 16 lanes j = 0..15
+// (reference: mel_features.py:71-92 stft_magnitude, :220-223 mel + log):
+//
+//   x[n], n < 400 windowed samples, zero-padded to 512 (mel_features.py:91-92)
+//   z[m] = x[2m] + i x[2m+1], m < 256            (real FFT through a half-size complex FFT)
+//   Z = FFT256(z) with 256 = 16 x 16:  m = 16 n1 + n2,  k = k1 + 16 k2
+//     phase 1  lane n2 :  A[k1] = W256^(n2 k1) * sum_n1 z[16 n1 + n2] W16^(n1 k1)
+//     exchange through LDS (16x16 transpose inside the group)
+//     phase 2  lane k1 :  Z[k1 + 16 k2] = sum_n2 A_n2[k1] W16^(n2 k2)
+//   2 X[k]     = (Z[k] + conj Z[256-k]) + w^k (Z[k] - conj Z[256-k]) / i,  w = e^(-2 pi i/512)
+//   2 X[256-k] = conj( (Z[k] + conj Z[256-k]) - w^k (...) / i )
+//     phase 3  lane j handles the 8 pairs k = 1 + j + 16 i  -> |2X| for bins 1..255
+//   mel[b] = sum_k (M[k][b] / 2) |2 X[k]| over the band's contiguous bin range (<= 17 bins)
+//     phase 4  lane j owns bands {j, 31-j, 32+j, 63-j} (26..31 non-zeros per lane)
+//   out[b] = log(mel[b] + 0.01)
+#ifndef MLA_LOGMEL_CORE_H
+#define MLA_LOGMEL_CORE_H
+
+#if defined(__HIPCC__)
+#define MLA_HD __host__ __device__ __forceinline__
+#else
+#define MLA_HD inline
+#endif
+
+namespace logmel {
+
+constexpr int kWin = 400, kHop = 160, kFft = 512, kBands = 64, kExFrames = 96;
+constexpr int kN1 = 13;                    // non-zero first-stage inputs: 32*n1 + 2*n2 < 400
+constexpr int kXchStride = 17;             // complex elements per exchange row (16 + 1 pad)
+constexpr int kSlot0 = 4, kSlot1 = 6, kSlot2 = 10, kSlot3 = 17;   // padded taps per band slot
+constexpr int kTaps = kSlot0 + kSlot1 + kSlot2 + kSlot3;          // 37
+
+// table layout (float indices) ------------------------------------------------------
+constexpr int kTabWindow = 0;              // 512 floats: Hann(400) then zeros
+constexpr int kTabTw256 = 512;             // 256 x (cos, -sin)(2 pi m / 256)
+constexpr int kTabTw512 = 1024;            // 129 x (cos, -sin)(2 pi k / 512), padded to 512
+constexpr int kTabMelStart = 1536;         // 16 lanes x 4 slots, int32 first bin of the slot
+constexpr int kMelRow = 40;                // padded per-lane weight row (16-byte multiples)
+constexpr int kPwRow = 16;                 // per-lane split twiddles: 8 x (re, im)
+constexpr int kTabMelW = 1600;             // 16 lanes x kMelRow floats, weights / 2 (zero padded)
+constexpr int kTabPw = kTabMelW + 16 * kMelRow;     // 16 lanes x kPwRow: w^(1 + j + 16 i)
+constexpr int kTabFloats = kTabPw + 16 * kPwRow;    // 2496
+constexpr int kLaneTabFloats = 16 * (kMelRow + kPwRow);   // contiguous [kTabMelW, kTabFloats): LDS-resident
+
+MLA_HD int band_of(int lane, int slot) {
+    return slot == 0 ? lane : slot == 1 ? 31 - lane : slot == 2 ? 32 + lane : 63 - lane;
+}
+
+// per-lane constants, loaded once per workgroup lifetime -------------------------------
+struct LaneConsts {
+    float win_re[kN1], win_im[kN1];        // window at samples 32 n1 + 2 j (+1)
+    float tw_re[16], tw_im[16];            // W256^(j k1)
+    int mel_start[4];
+};
+
+MLA_HD void load_consts(LaneConsts& c, const float* tab, int j) {
+    _Pragma("unroll") for (int n1 = 0; n1 < kN1; ++n1) {
+        c.win_re[n1] = tab[kTabWindow + 32 * n1 + 2 * j];
+        c.win_im[n1] = tab[kTabWindow + 32 * n1 + 2 * j + 1];
+    }
+    _Pragma("unroll") for (int k1 = 0; k1 < 16; ++k1) {
+        c.tw_re[k1] = tab[kTabTw256 + 2 * (j * k1)];
+        c.tw_im[k1] = tab[kTabTw256 + 2 * (j * k1) + 1];
+    }
+    const int* starts = reinterpret_cast<const int*>(tab + kTabMelStart);
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) c.mel_start[s] = starts[4 * j + s];
+}
+
+// 4-point forward DFT (W4 = -i), in place on elements (0,1,2,3) of the argument list ------
+MLA_HD void dft4(float& r0, float& i0, float& r1, float& i1, float& r2, float& i2, float& r3, float& i3) {
+    const float t0r = r0 + r2, t0i = i0 + i2, t1r = r0 - r2, t1i = i0 - i2;
+    const float t2r = r1 + r3, t2i = i1 + i3, t3r = r1 - r3, t3i = i1 - i3;
+    r0 = t0r + t2r; i0 = t0i + t2i;
+    r2 = t0r - t2r; i2 = t0i - t2i;
+    r1 = t1r + t3i; i1 = t1i - t3r;       // t1 - i t3
+    r3 = t1r - t3i; i3 = t1i + t3r;       // t1 + i t3
+}
+// same with the 4th input known to be zero (outputs written to all four)
+MLA_HD void dft4_z3(float& r0, float& i0, float& r1, float& i1, float& r2, float& i2, float& r3, float& i3) {
+    const float t0r = r0 + r2, t0i = i0 + i2, t1r = r0 - r2, t1i = i0 - i2;
+    const float xr = r1, xi = i1;
+    r0 = t0r + xr; i0 = t0i + xi;
+    r2 = t0r - xr; i2 = t0i - xi;
+    r1 = t1r + xi; i1 = t1i - xr;
+    r3 = t1r - xi; i3 = t1i + xr;
+}
+
+MLA_HD void cmul(float& r, float& i, float p, float q) {   // (r + i i) *= (p + i q)
+    const float nr = r * p - i * q, ni = r * q + i * p;
+    r = nr; i = ni;
+}
+
+// 16-point forward DFT of re/im[0..15] (index n = 4a + b). Output X[k], k = c + 4d, is left
+// at element 4c + d (base-4 digit reversal); use dr16(k) to address it.
+// LAST3_ZERO: inputs 13, 14, 15 are zero (first stage: only 13 non-zero n1).
+MLA_HD constexpr int dr16(int k) { return 4 * (k & 3) + (k >> 2); }
+
+template <bool LAST3_ZERO>
+MLA_HD void dft16(float* re, float* im) {
+    constexpr float C1 = 0.92387953251128673848f, S1 = 0.38268343236508978178f, R = 0.70710678118654752440f;
+    // step 1: DFT4 over a for each b -> y_b[c] at element 4c + b
+    dft4(re[0], im[0], re[4], im[4], re[8], im[8], re[12], im[12]);
+    if (LAST3_ZERO) {
+        dft4_z3(re[1], im[1], re[5], im[5], re[9], im[9], re[13], im[13]);
+        dft4_z3(re[2], im[2], re[6], im[6], re[10], im[10], re[14], im[14]);
+        dft4_z3(re[3], im[3], re[7], im[7], re[11], im[11], re[15], im[15]);
+    } else {
+        dft4(re[1], im[1], re[5], im[5], re[9], im[9], re[13], im[13]);
+        dft4(re[2], im[2], re[6], im[6], re[10], im[10], re[14], im[14]);
+        dft4(re[3], im[3], re[7], im[7], re[11], im[11], re[15], im[15]);
+    }
+    // step 2: y_b[c] *= W16^(b c), element 4c + b; W16^m = (cos, -sin)(2 pi m / 16)
+    cmul(re[5], im[5], C1, -S1);                                   // b=1,c=1: m=1
+    { const float a = re[6], b = im[6]; re[6] = R * (a + b); im[6] = R * (b - a); }      // m=2
+    cmul(re[7], im[7], S1, -C1);                                   // b=3,c=1: m=3
+    { const float a = re[9], b = im[9]; re[9] = R * (a + b); im[9] = R * (b - a); }      // b=1,c=2: m=2
+    { const float a = re[10], b = im[10]; re[10] = b; im[10] = -a; }                     // m=4: -i
+    { const float a = re[11], b = im[11]; re[11] = R * (b - a); im[11] = -R * (a + b); } // m=6
+    cmul(re[13], im[13], S1, -C1);                                 // b=1,c=3: m=3
+    { const float a = re[14], b = im[14]; re[14] = R * (b - a); im[14] = -R * (a + b); } // m=6
+    cmul(re[15], im[15], -C1, S1);                                 // b=3,c=3: m=9
+    // step 3: DFT4 over b for each c: elements 4c .. 4c+3 -> X[c + 4d] at 4c + d
+    dft4(re[0], im[0], re[1], im[1], re[2], im[2], re[3], im[3]);
+    dft4(re[4], im[4], re[5], im[5], re[6], im[6], re[7], im[7]);
+    dft4(re[8], im[8], re[9], im[9], re[10], im[10], re[11], im[11]);
+    dft4(re[12], im[12], re[13], im[13], re[14], im[14], re[15], im[15]);
+}
+
+// phase 1: lane j = n2. `frame` points at the frame's first sample in the PCM staging
+// buffer (float, 8-byte aligned: frame starts are multiples of 160 samples). Writes
+// A[k1] * W256^(j k1) to xch[k1 * 17 + j] (float2 = re, im).
+MLA_HD void phase1(const LaneConsts& c, int j, const float* frame, float* xch) {
+    float re[16], im[16];
+    _Pragma("unroll") for (int n1 = 0; n1 < 12; ++n1) {
+        re[n1] = frame[32 * n1 + 2 * j] * c.win_re[n1];
+        im[n1] = frame[32 * n1 + 2 * j + 1] * c.win_im[n1];
+    }
+    if (j < 8) {      // samples 384 + 2j (+1) < 400; beyond: zero padding, never read
+        re[12] = frame[384 + 2 * j] * c.win_re[12];
+        im[12] = frame[384 + 2 * j + 1] * c.win_im[12];
+    } else {
+        re[12] = 0.f; im[12] = 0.f;
+    }
+    re[13] = re[14] = re[15] = 0.f;
+    im[13] = im[14] = im[15] = 0.f;
+    dft16<true>(re, im);
+    _Pragma("unroll") for (int k1 = 0; k1 < 16; ++k1) {
+        float r = re[dr16(k1)], i = im[dr16(k1)];
+        if (k1) cmul(r, i, c.tw_re[k1], c.tw_im[k1]);
+        xch[2 * (k1 * kXchStride + j)] = r;
+        xch[2 * (k1 * kXchStride + j) + 1] = i;
+    }
+}
+
+// phase 2a: lane j = k1 gathers its row of the exchange buffer (all lanes of the group must
+// have finished phase 1). Split from 2b because the Z image written in 2b aliases xch.
+MLA_HD void phase2_read(int j, const float* xch, float* re, float* im) {
+    _Pragma("unroll") for (int n2 = 0; n2 < 16; ++n2) {
+        re[n2] = xch[2 * (j * kXchStride + n2)];
+        im[n2] = xch[2 * (j * kXchStride + n2) + 1];
+    }
+}
+// phase 2b: second radix-16, then Z[k1 + 16 k2] -> zbuf[k] (float2), k linear 0..255.
+// (All lanes of the group must have finished phase2_read before any lane writes.)
+MLA_HD void phase2_write(int j, float* re, float* im, float* zbuf) {
+    dft16<false>(re, im);
+    _Pragma("unroll") for (int k2 = 0; k2 < 16; ++k2) {
+        zbuf[2 * (j + 16 * k2)] = re[dr16(k2)];
+        zbuf[2 * (j + 16 * k2) + 1] = im[dr16(k2)];
+    }
+}
+
+MLA_HD float fast_sqrt(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_sqrtf(v);
+#else
+    return __builtin_sqrtf(v);
+#endif
+}
+
+// phase 3: |2 X[k]| and |2 X[256-k]| for k = 1 + j + 16 i  ->  mag[1..255]
+// pw: this lane's kPwRow split twiddles (table row kTabPw + kPwRow * j).
+MLA_HD void phase3(int j, const float* zbuf, float* mag, const float* pw) {
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {
+        const int k = 1 + j + 16 * i;
+        const float a = zbuf[2 * k], b = zbuf[2 * k + 1];
+        const float p = zbuf[2 * (256 - k)], q = zbuf[2 * (256 - k) + 1];
+        const float er = a + p, ei = b - q;          // 2 E[k]  = Z[k] + conj Z[256-k]
+        float orr = b + q, oi = p - a;                // 2 O[k]  = (Z[k] - conj Z[256-k]) / i
+        cmul(orr, oi, pw[2 * i], pw[2 * i + 1]);        // w^k * 2 O[k]
+        const float ur = er + orr, ui = ei + oi, vr = er - orr, vi = ei - oi;
+        mag[k] = fast_sqrt(ur * ur + ui * ui);
+        mag[256 - k] = fast_sqrt(vr * vr + vi * vi);
+    }
+}
+
+// phase 4: four mel bands per lane, natural log with the reference's 0.01 offset.
+// melw: this lane's kMelRow weights (table row kTabMelW + kMelRow * j).
+MLA_HD void phase4(const LaneConsts& c, int j, const float* mag, const float* melw, float* out4) {
+    constexpr int first[4] = {0, kSlot0, kSlot0 + kSlot1, kSlot0 + kSlot1 + kSlot2};
+    constexpr int count[4] = {kSlot0, kSlot1, kSlot2, kSlot3};
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {
+        const float* m = mag + c.mel_start[s];
+        float acc = 0.f;
+        _Pragma("unroll") for (int t = 0; t < count[s]; ++t) acc += melw[first[s] + t] * m[t];
+        out4[s] = __builtin_logf(acc + 0.01f);
+    }
+}
+
+}  // namespace logmel
+#endif

@@ -1,0 +1,92 @@
+"""Host side of the HIP audio front-end: device tables, buffer plumbing, ctypes calls.
+
+PyTorch is used for device memory and streams only; all arithmetic is in csrc/logmel.hip.
+"""
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_tables = {}
+
+
+def device_tables(device):
+    """Constant tables of the fused kernel, built by the library in float64 and uploaded once."""
+    key = str(device)
+    if key not in _tables:
+        L = _lib.lib()
+        n = int(L.mla_logmel_table_floats())
+        host = np.zeros(n, dtype=np.float32)
+        _lib.check(L.mla_logmel_build_tables(host.ctypes.data_as(ctypes.c_void_p)))
+        _tables[key] = torch.from_numpy(host).to(device)
+    return _tables[key]
+
+
+def counts(n_samples):
+    """(stft_frames, examples) for a 16 kHz waveform; ValueError where the reference raises."""
+    L = _lib.lib()
+    f, e = ctypes.c_int64(), ctypes.c_int64()
+    rc = L.mla_logmel_counts(int(n_samples), ctypes.byref(f), ctypes.byref(e))
+    if rc == _lib.E_SHORT:
+        raise ValueError("negative dimensions are not allowed")
+    _lib.check(rc)
+    return f.value, e.value
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("the HIP front-end needs a GPU (cuda:0); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def as_device_mono(data):
+    """ndarray / tensor, 1-D or (samples, channels) -> 1-D device tensor, float32 or int16.
+
+    int16 stays int16 (the kernel scales by 1/32768 itself). Multi-channel input is averaged
+    over axis 1 as vggish_input.py:49-50 does; that mean is the one host-side reduction kept
+    outside the kernel (stereo input is not part of the benchmarked path).
+    """
+    dev = _device()
+    if isinstance(data, np.ndarray):
+        if data.ndim > 1:
+            data = data.mean(axis=1) if data.dtype != np.int16 else data.astype(np.float64).mean(axis=1) / 32768.0
+        if data.dtype != np.int16:
+            data = data.astype(np.float32, copy=False)
+        return torch.from_numpy(np.ascontiguousarray(data)).to(dev)
+    t = data
+    if t.dim() > 1:
+        t = (t.double().mean(dim=1) / (32768.0 if t.dtype == torch.int16 else 1.0)).float()
+    if t.dtype != torch.int16:
+        t = t.float()
+    return t.to(dev).contiguous()
+
+
+def waveforms_to_examples(pcm, out_dtype=torch.float32, out=None):
+    """(W, n) device PCM (float32 or int16) -> (W * N, 96, 64) examples, waveform-major."""
+    assert pcm.dim() == 2 and pcm.is_cuda and pcm.stride(1) == 1
+    n_wave, n_samples = pcm.shape
+    _, n_ex = counts(n_samples)
+    if out is None:
+        out = torch.empty((n_wave * n_ex, 96, 64), dtype=out_dtype, device=pcm.device)
+    else:
+        assert out.is_contiguous() and out.numel() == n_wave * n_ex * 96 * 64 and out.dtype == out_dtype
+    if n_wave * n_ex == 0:
+        return out
+    pcm_code = {torch.float32: _lib.F32, torch.int16: _lib.I16}[pcm.dtype]
+    out_code = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}[out_dtype]
+    tab = device_tables(pcm.device)
+    _lib.check(_lib.lib().mla_logmel_examples(
+        ctypes.c_void_p(pcm.data_ptr()), pcm_code, n_wave, n_samples, pcm.stride(0),
+        ctypes.c_void_p(tab.data_ptr()), ctypes.c_void_p(out.data_ptr()), out_code, _lib.stream_ptr()))
+    return out
+
+
+def stft_magnitude(signal, fft_length, hop_length, window_length):
+    raise NotImplementedError("stand-alone stft_magnitude kernel not built yet")
+
+
+def log_mel_spectrogram(data, audio_sample_rate, log_offset, window_length_secs, hop_length_secs, **kwargs):
+    raise NotImplementedError("stand-alone log_mel_spectrogram kernel not built yet")

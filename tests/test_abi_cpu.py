@@ -1,0 +1,115 @@
+"""CPU tests of the C-ABI library and of the kernel arithmetic simulated on the host.
+
+No compute entry point is called here (no GPU in this container): the library must load,
+export every symbol include/mla_hip.h declares, and its host-side helpers (frame counts,
+constant tables) must agree with the oracle. The per-lane kernel math (csrc/logmel_core.h)
+is compiled with g++ and run lane by lane against the oracle.
+"""
+
+import ctypes
+import importlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import PKG, ROOT
+from oracle import frontend as ofe
+
+
+@pytest.fixture(scope="module")
+def L():
+    build = importlib.import_module(PKG + ".build")
+    build.build(verbose=False)
+    return importlib.import_module(PKG + "._lib")
+
+
+def test_library_exports_every_declared_symbol(L):
+    lib = L.lib()
+    names = L.declared_symbols()
+    assert "mla_logmel_examples" in names and len(names) >= 7
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.mla_abi_version() >= 1
+
+
+def test_counts_match_reference_table(L, golden):
+    lib = L.lib()
+    f, e = ctypes.c_int64(), ctypes.c_int64()
+    for n, n_ex, raised in golden("frontend")["count_table"]:
+        rc = lib.mla_logmel_counts(int(n), ctypes.byref(f), ctypes.byref(e))
+        if raised:
+            assert rc == L.E_SHORT and b"ValueError" in lib.mla_last_error()
+        else:
+            assert rc == 0 and e.value == n_ex and f.value == ofe.num_frames(int(n), 400, 160)
+    for n in range(0, 40000, 37):
+        rc = lib.mla_logmel_counts(n, ctypes.byref(f), ctypes.byref(e))
+        if n < 240:
+            assert rc == L.E_SHORT
+        else:
+            assert rc == 0 and (f.value, e.value) == (ofe.num_frames(n, 400, 160), ofe.num_examples(n))
+
+
+def test_tables_match_oracle(L):
+    lib = L.lib()
+    win, mel = np.zeros(400), np.zeros((257, 64))
+    assert lib.mla_logmel_reference_tables(win.ctypes.data_as(ctypes.c_void_p), mel.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert np.array_equal(win, ofe.periodic_hann(400))
+    ref = ofe.mel_matrix(64, 257, 16000, 125.0, 7500.0)
+    np.testing.assert_allclose(mel, ref, rtol=0, atol=1e-15)
+    assert np.array_equal(mel != 0, ref != 0)
+    n = lib.mla_logmel_table_floats()
+    tab = np.zeros(n, dtype=np.float32)
+    assert lib.mla_logmel_build_tables(tab.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert np.array_equal(tab[:400], win.astype(np.float32)) and not tab[400:512].any()
+    m = np.arange(256)
+    np.testing.assert_allclose(tab[512:1024:2], np.cos(2 * np.pi * m / 256), atol=1e-7)
+    np.testing.assert_allclose(tab[513:1024:2], -np.sin(2 * np.pi * m / 256), atol=1e-7)
+    # sparse per-lane mel rows reproduce the dense matrix (weights are stored halved)
+    starts = tab[1536:1600].view(np.int32).reshape(16, 4)
+    rows = tab[1600:1600 + 16 * 40].reshape(16, 40)
+    dense = np.zeros((257, 64))
+    counts = (4, 6, 10, 17)
+    for lane in range(16):
+        bands = (lane, 31 - lane, 32 + lane, 63 - lane)
+        first = 0
+        for s in range(4):
+            assert 1 <= starts[lane, s] and starts[lane, s] + counts[s] <= 256
+            dense[starts[lane, s]:starts[lane, s] + counts[s], bands[s]] = 2.0 * rows[lane, first:first + counts[s]]
+            first += counts[s]
+    np.testing.assert_allclose(dense, ref, rtol=1e-7, atol=0)
+
+
+@pytest.fixture(scope="module")
+def hostsim(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("hostsim") / "hostsim.so")
+    src = os.path.join(ROOT, PKG, "csrc", "logmel_hostsim.cpp")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src], check=True)
+    lib = ctypes.CDLL(so)
+    lib.hostsim_examples.restype = ctypes.c_int64
+    lib.hostsim_examples.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    return lib
+
+
+def mel_domain_close(got, ref, rel=2e-5, floor=2e-6):
+    """|mel - mel_ref| <= rel*mel_ref + floor*max(mel_ref of the frame): float32 dynamic range
+    (about -115 dB below the frame's strongest band), see DESIGN.md "front-end tolerance"."""
+    g, r = np.exp(got.astype(np.float64)) - 0.01, np.exp(ref) - 0.01
+    bound = rel * r + floor * r.max(axis=-1, keepdims=True) + 1e-9
+    return bool(np.all(np.abs(g - r) <= bound)), float(np.max(np.abs(g - r) / bound))
+
+
+def test_kernel_math_on_host_matches_oracle(hostsim, mk):
+    for name, wav in mk.test_waveforms().items():
+        if wav.ndim > 1:
+            wav = wav.mean(axis=1)
+        x = np.ascontiguousarray(wav.astype(np.float32))
+        ref = ofe.waveform_to_examples(wav)
+        out = np.zeros(ref.shape, dtype=np.float32)
+        n = hostsim.hostsim_examples(x.ctypes.data_as(ctypes.c_void_p), len(x), out.ctypes.data_as(ctypes.c_void_p))
+        assert n == ref.shape[0], name
+        ok, worst = mel_domain_close(out, ref)
+        assert ok, (name, worst)
+        if name.startswith(("noise", "stereo", "silence")):       # broadband: log-domain bound
+            assert np.abs(out - ref).max() <= 1e-4, name

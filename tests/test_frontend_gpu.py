@@ -1,0 +1,122 @@
+"""GPU parity tests of the HIP front-end (through the C ABI) against the oracle and the
+golden vectors the reference produced."""
+
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PKG
+from oracle import frontend as ofe
+from test_abi_cpu import mel_domain_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vi():
+    return importlib.import_module(PKG + ".torchvggish.vggish_input")
+
+
+@pytest.fixture(scope="module")
+def fe():
+    return importlib.import_module(PKG + ".frontend")
+
+
+def test_waveform_to_examples_matches_reference_golden(vi, golden, mk):
+    g = golden("frontend")
+    for name, wav in mk.test_waveforms().items():
+        t = vi.waveform_to_examples(wav, 16000)
+        assert t.is_cuda and t.dtype == torch.float32 and t.requires_grad
+        assert tuple(t.shape) == tuple(g["tensor_shape/" + name]), name
+        got = t.detach().cpu().numpy()[:, 0]
+        ref = ofe.waveform_to_examples(wav)
+        assert np.array_equal(ref.astype(np.float32), g["ex32/" + name])      # oracle == reference
+        ok, worst = mel_domain_close(got, ref)
+        assert ok, (name, worst)
+        if name.startswith(("noise", "stereo", "silence", "quiet")):
+            assert np.abs(got - ref).max() <= 1e-4, (name, np.abs(got - ref).max())
+        arr = vi.waveform_to_examples(wav, 16000, return_tensor=False)
+        assert isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.shape == ref.shape
+        assert np.array_equal(arr.astype(np.float32), got)
+
+
+def test_short_inputs_behave_like_the_reference(vi, golden):
+    for n, n_ex, raised in golden("frontend")["count_table"]:
+        if n > 20000:
+            continue
+        if raised:
+            with pytest.raises(ValueError):
+                vi.waveform_to_examples(np.zeros(int(n)), 16000)
+        else:
+            t = vi.waveform_to_examples(np.zeros(int(n)), 16000)
+            assert tuple(t.shape) == (n_ex, 1, 96, 64)
+            if n_ex:
+                assert torch.allclose(t, torch.full_like(t, float(np.log(np.float32(0.01)))), atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        vi.waveform_to_examples(np.zeros(16000), 22050)
+
+
+def test_batched_unaligned_int16_and_bf16(fe, W):
+    dev = torch.device("cuda")
+    n = 47003                                        # odd length: rows are not 16-byte aligned
+    waves = W.waveform(31, n, 5, dtype=np.float64)
+    ref = ofe.batch_examples(waves)
+    pcm = torch.from_numpy(waves.astype(np.float32)).to(dev)
+    got = fe.waveforms_to_examples(pcm).cpu().numpy()
+    assert got.shape == ref.shape == (15, 96, 64)
+    assert np.abs(got - ref).max() <= 1e-4
+    # same data behind an offset view (scalar-load path) gives the same bits as an aligned copy
+    padded = torch.zeros((5, n + 8), dtype=torch.float32, device=dev)
+    padded[:, 1:n + 1] = pcm
+    view = padded[:, 1:n + 1]
+    assert view.data_ptr() % 16 != 0
+    assert torch.equal(fe.waveforms_to_examples(view), torch.from_numpy(got).to(dev))
+    # int16 PCM: exact 1/32768 scaling in-kernel (vggish_input.py:98)
+    i16 = np.round(waves * 20000).astype(np.int16)
+    ref16 = ofe.batch_examples(i16 / 32768.0)
+    got16 = fe.waveforms_to_examples(torch.from_numpy(i16).to(dev)).cpu().numpy()
+    assert np.abs(got16 - ref16).max() <= 1e-4
+    # bf16 output is the f32 result rounded to nearest-even
+    gb = fe.waveforms_to_examples(pcm, out_dtype=torch.bfloat16)
+    assert torch.equal(gb.cpu(), torch.from_numpy(got).to(torch.bfloat16))
+
+
+def test_wave_level_sync_equals_block_barrier_build(fe, W):
+    """The shipped kernel orders its intra-group LDS hand-offs with wave-level fences; the
+    MLA_LOGMEL_SYNC=block build uses full workgroup barriers. Results must be bit-identical."""
+    pcm = torch.from_numpy(W.waveform(32, 160000, 64)).cuda()
+    a = fe.waveforms_to_examples(pcm)
+    os.environ["MLA_LOGMEL_SYNC"] = "block"
+    try:
+        b = fe.waveforms_to_examples(pcm)
+    finally:
+        del os.environ["MLA_LOGMEL_SYNC"]
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    ref = ofe.batch_examples(pcm[:2].cpu().numpy().astype(np.float64))
+    assert np.abs(a[:20].cpu().numpy() - ref).max() <= 1e-4
+
+
+def test_full_size_properties(fe, W):
+    """BASELINE config sizes: 1024 bags x 10 s. Size-independent properties: (i) batching does
+    not change any bit (each waveform alone == inside the batch), (ii) shifting a waveform by
+    one example hop (15 360 samples) shifts the examples by one, bit-exactly, (iii) rerun is
+    deterministic."""
+    n_wave, n = 1024, 160000
+    base = torch.from_numpy(W.waveform(33, n + 15360, 8)).cuda()
+    pcm = base[:, :n].repeat(n_wave // 8, 1).contiguous()
+    out = fe.waveforms_to_examples(pcm)
+    assert tuple(out.shape) == (n_wave * 10, 96, 64) and bool(torch.isfinite(out).all())
+    assert torch.equal(out, fe.waveforms_to_examples(pcm))
+    first = out[:80]
+    for rep in (1, 57, 127):
+        assert torch.equal(out[rep * 80:(rep + 1) * 80], first)
+    solo = fe.waveforms_to_examples(pcm[3:4])
+    assert torch.equal(solo, out[30:40])
+    shifted = fe.waveforms_to_examples(base[:, 15360:].contiguous())
+    assert torch.equal(shifted.view(8, 10, 96, 64)[:, :9], first.view(8, 10, 96, 64)[:, 1:])
+    ref = ofe.batch_examples(base[:1, :n].cpu().numpy().astype(np.float64))
+    assert np.abs(first[:10].cpu().numpy() - ref).max() <= 1e-4
