@@ -46,6 +46,18 @@ def lib():
         L.mla_logmel_build_tables.argtypes = [vp]
         L.mla_logmel_reference_tables.argtypes = [vp, vp]
         L.mla_logmel_examples.argtypes = [vp, ci, i64, i64, i64, vp, vp, ci, vp]
+        cf = ctypes.c_float
+        L.mla_conv_repack_weights.argtypes = [vp, i64, i64, vp, ci, vp]
+        L.mla_convert_f32.argtypes = [vp, vp, i64, ci, vp]
+        L.mla_convert_bf16_to_f32.argtypes = [vp, vp, i64, vp]
+        L.mla_vggish_conv1.argtypes = [vp, ci, i64, vp, vp, vp, ci, vp]
+        L.mla_vggish_conv.argtypes = [ci, vp, vp, vp, vp, i64, ci, vp]
+        L.mla_linear.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, ci, ci, ci, vp]
+        L.mla_linear_small.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, vp]
+        L.mla_bn_stats_workspace_bytes.restype = i64
+        L.mla_bn_stats.argtypes = [vp, i64, i64, i64, ci, ci, vp, vp, vp, vp, vp, cf, vp]
+        L.mla_bn_apply.argtypes = [vp, i64, vp, i64, i64, i64, ci, ci, vp, vp, vp, vp, cf, ci, vp, cf, vp]
+        L.mla_attention_pool.argtypes = [vp, i64, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, vp, i64, vp, vp, vp]
         _lib = L
     return _lib
 

@@ -1,0 +1,362 @@
+// conv.hip -- VGGish feature stack on gfx950 (reference: vggish.py:108-118 make_layers(),
+// applied at vggish.py:22): six 3x3/pad-1 convolutions + ReLU with four 2x2 max-pools, NHWC.
+//
+//   conv1 (Cin = 1)      dedicated VALU kernel, fused bias + ReLU + 2x2 pool: 0.4 % of the FLOPs
+//                        but the largest activation, so it is written for the memory pipe
+//                        (one pooled pixel x 64 channels per lane, 128 B contiguous stores).
+//   conv2 .. conv4_2     implicit GEMM on the matrix cores: M = pixels, N = Cout, K = 9 Cin.
+//                        bf16 (v_mfma_f32_16x16x32_bf16) or exact-f32 (v_mfma_f32_16x16x4_f32)
+//                        from ONE source; fused bias + ReLU (+ 2x2 max-pool) epilogue, so the
+//                        un-pooled activation never goes to HBM and the NHWC output makes the
+//                        reference's NCHW->NHWC flatten (vggish.py:26-29) a no-op.
+//
+// Roofline: MFMA. Algorithmic work 2 * H*W * Cout * 9*Cin FLOP per frame and layer
+// (SURVEY.md section 8a, row a9): 226.5 / 226.5 / 453.0 / 226.5 / 453.0 MFLOP for conv2..conv4_2.
+//
+// Workgroup = 512 threads = 8 waves as 2 (M) x 4 (N); output tile 192 pixels x (64 * NS)
+// channels; each wave owns 6 x NS 16x16 accumulator tiles. The input patch (tile rows + halo,
+// one 128-byte channel chunk per pixel) is parked in LDS ONCE per channel chunk and serves all
+// nine taps as shifted reads -- no im2col copy; weights stream through a double-buffered LDS
+// tile per (tap, chunk) with the next slice in flight (registers) behind the MFMAs. M-subtiles
+// are laid out so that 2x2 pooling is lane-local in the accumulator registers:
+//   W >= 16 : an m-subtile = 16 consecutive x of one image row; rows y / y+1 are the wave's
+//             subtiles i / i+1, x pairs are accumulator registers (0,1) / (2,3);
+//   W == 8  : an m-subtile = 8 x of image a + 8 x of image a+1 (same row).
+#include "common.h"
+#include "mma_core.h"
+
+namespace {
+
+using namespace mma;
+
+constexpr int kThreads = 512, kWavesN = 4, kMS = 6;
+
+template <typename T, int CIN_, int COUT_, int H_, int W_, bool POOL_, int NS_>
+struct Cfg {
+    using elem = T;
+    static constexpr int CIN = CIN_, COUT = COUT_, H = H_, W = W_, NS = NS_;
+    static constexpr bool POOL = POOL_;
+    static constexpr int SEGW = W >= 16 ? 16 : 8;          // pixels of one image row per m-subtile
+    static constexpr int SEGS = W / SEGW;                   // subtiles per tile row (2 for W = 32)
+    static constexpr int IMGS = 16 / SEGW;                  // images per tile (2 for W = 8)
+    static constexpr int TH = 12 / SEGS;                    // tile rows: 12 m-subtiles per tile
+    static constexpr int PW = W + 2, PH = TH + 2;           // patch with halo
+    static constexpr int BN = kWavesN * NS * 16;
+    static constexpr int KC = Elem<T>::kPerRow;             // channels per 128-byte chunk
+    static constexpr int A_BYTES = IMGS * PH * PW * kRowBytes;
+    static constexpr int B_BYTES = BN * kRowBytes;
+    static constexpr int LDS_BYTES = A_BYTES + 2 * B_BYTES;
+    static constexpr int TILES_Y = H / TH;
+    static constexpr int HO = POOL ? H / 2 : H, WO = POOL ? W / 2 : W;
+    static_assert(W == 32 || W == 16 || W == 8, "tile mapping covers the VGGish widths");
+    static_assert(H % TH == 0 && CIN % KC == 0 && COUT % BN == 0, "shape must tile exactly");
+    static_assert((PW * kRowBytes) % 256 == 0, "row pitch must keep the bank swizzle invariant");
+    static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
+};
+
+template <typename C>
+__device__ __forceinline__ int a_swizzle(int xh, int img) {
+    return C::SEGW == 16 ? ((xh >> 1) & 7) : (((xh >> 1) & 3) | ((img & 1) << 2));
+}
+
+template <typename C>
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const typename C::elem* __restrict__ in,
+                                                               const typename C::elem* __restrict__ wgt,
+                                                               const float* __restrict__ bias,
+                                                               typename C::elem* __restrict__ out, int n_img) {
+    using T = typename C::elem;
+    constexpr int PER = Elem<T>::kPerChunk;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;
+    char* sB = smem + C::A_BYTES;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+    const int ty = blockIdx.x % C::TILES_Y;
+    const int img0 = (blockIdx.x / C::TILES_Y) * C::IMGS;
+    const int y_tile = ty * C::TH;
+    const int n0 = blockIdx.y * C::BN;
+
+    // this lane's pixel inside the tile (A-operand row r of every m-subtile of the wave)
+    const int l_img = C::SEGW == 8 ? (r >> 3) : 0;
+    const int l_x = C::SEGW == 8 ? (r & 7) : ((C::SEGS == 2 ? wm * 16 : 0) + r);
+    const int l_y0 = C::SEGS == 2 ? 0 : kMS * wm;
+    int abase[3];
+    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {
+        const int xh = l_x + kx;
+        abase[kx] = ((l_img * C::PH + l_y0) * C::PW + xh) * kRowBytes + 16 * (q ^ a_swizzle<C>(xh, l_img));
+    }
+    const int bbase = (wn * C::NS * 16 + r) * kRowBytes + 16 * (q ^ ((r >> 1) & 7));
+
+    f32x4 acc[kMS][C::NS];
+    _Pragma("unroll") for (int i = 0; i < kMS; ++i)
+        _Pragma("unroll") for (int j = 0; j < C::NS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int A_PIECES = C::IMGS * C::PH * C::PW * 8;
+    constexpr int A_PASSES = (A_PIECES + kThreads - 1) / kThreads;
+
+    for (int c0 = 0; c0 < C::CIN; c0 += C::KC) {
+        __syncthreads();                      // every wave is done with sA / sB of the previous chunk
+        {   // input patch: global -> registers -> LDS (zero outside the image / past the batch)
+            u32x4 v[A_PASSES];
+            int dst[A_PASSES];
+            _Pragma("unroll") for (int p = 0; p < A_PASSES; ++p) {
+                const int piece = t + kThreads * p;
+                const int ch = piece & 7, pix = piece >> 3;
+                const int xh = pix % C::PW, rest = pix / C::PW;
+                const int yh = rest % C::PH, im = rest / C::PH;
+                const int gy = y_tile + yh - 1, gx = xh - 1, gi = img0 + im;
+                const bool ok = piece < A_PIECES && gy >= 0 && gy < C::H && gx >= 0 && gx < C::W && gi < n_img;
+                dst[p] = piece < A_PIECES
+                             ? ((im * C::PH + yh) * C::PW + xh) * kRowBytes + 16 * (ch ^ a_swizzle<C>(xh, im))
+                             : -1;
+                v[p] = zero16();
+                if (ok) {
+                    const size_t off = ((size_t(gi) * C::H + gy) * C::W + gx) * C::CIN + c0 + ch * PER;
+                    v[p] = *reinterpret_cast<const u32x4*>(in + off);
+                }
+            }
+            _Pragma("unroll") for (int p = 0; p < A_PASSES; ++p)
+                if (dst[p] >= 0) lds_write16(sA, dst[p], v[p]);
+        }
+        _Pragma("unroll") for (int p = 0; p < C::NS; ++p) {      // weights of tap 0 -> buffer 0
+            const int piece = t + kThreads * p, n = piece >> 3, ch = piece & 7;
+            const size_t off = (size_t(n0 + n) * 9 + 0) * C::CIN + c0 + ch * PER;
+            lds_write16(sB, tile_off(n, ch), *reinterpret_cast<const u32x4*>(wgt + off));
+        }
+        __syncthreads();
+
+        _Pragma("unroll") for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3, buf = tap & 1;
+            u32x4 breg[C::NS];
+            if (tap < 8) {                    // next tap's weights: in flight behind the MFMAs
+                _Pragma("unroll") for (int p = 0; p < C::NS; ++p) {
+                    const int piece = t + kThreads * p, n = piece >> 3, ch = piece & 7;
+                    const size_t off = (size_t(n0 + n) * 9 + (tap + 1)) * C::CIN + c0 + ch * PER;
+                    breg[p] = *reinterpret_cast<const u32x4*>(wgt + off);
+                }
+            }
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {
+                u32x4 af[kMS], bf[C::NS];
+                _Pragma("unroll") for (int i = 0; i < kMS; ++i)
+                    af[i] = lds_read16(sA, (abase[kx] ^ (ks << 6)) + (i + ky) * C::PW * kRowBytes);
+                _Pragma("unroll") for (int j = 0; j < C::NS; ++j)
+                    bf[j] = lds_read16(sB, buf * C::B_BYTES + (bbase ^ (ks << 6)) + j * 16 * kRowBytes);
+                _Pragma("unroll") for (int i = 0; i < kMS; ++i)
+                    _Pragma("unroll") for (int j = 0; j < C::NS; ++j) mma_step<T>(af[i], bf[j], acc[i][j]);
+            }
+            if (tap < 8) {
+                _Pragma("unroll") for (int p = 0; p < C::NS; ++p) {
+                    const int piece = t + kThreads * p, n = piece >> 3, ch = piece & 7;
+                    lds_write16(sB, (buf ^ 1) * C::B_BYTES + tile_off(n, ch), breg[p]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // epilogue: bias + ReLU (+ lane-local 2x2 max-pool; max commutes with the monotone bias+ReLU)
+    _Pragma("unroll") for (int j = 0; j < C::NS; ++j) {
+        const int n = n0 + (wn * C::NS + j) * 16 + r;
+        const float b = bias[n];
+        if (C::POOL) {
+            _Pragma("unroll") for (int ip = 0; ip < kMS / 2; ++ip) {
+                const f32x4 u = acc[2 * ip][j], d = acc[2 * ip + 1][j];
+                const float p0 = fmaxf(fmaxf(u.x, u.y), fmaxf(d.x, d.y));
+                const float p1 = fmaxf(fmaxf(u.z, u.w), fmaxf(d.z, d.w));
+                const int yo = (y_tile + l_y0 + 2 * ip) >> 1;
+                const int img = img0 + (C::SEGW == 8 ? (q >> 1) : 0);
+                const int xo = C::SEGW == 8 ? 2 * (q & 1) : (((C::SEGS == 2 ? wm * 16 : 0) + 4 * q) >> 1);
+                if (img < n_img) {
+                    T* o = out + ((size_t(img) * C::HO + yo) * C::WO + xo) * C::COUT + n;
+                    store_elem<T>(o, fmaxf(p0 + b, 0.f));
+                    store_elem<T>(o + C::COUT, fmaxf(p1 + b, 0.f));
+                }
+            }
+        } else {
+            _Pragma("unroll") for (int i = 0; i < kMS; ++i) {
+                const int y = y_tile + l_y0 + i;
+                const float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {
+                    const int rr = 4 * q + e;
+                    const int img = img0 + (C::SEGW == 8 ? (rr >> 3) : 0);
+                    const int x = C::SEGW == 8 ? (rr & 7) : ((C::SEGS == 2 ? wm * 16 : 0) + rr);
+                    if (img < n_img)
+                        store_elem<T>(out + ((size_t(img) * C::H + y) * C::W + x) * C::COUT + n, fmaxf(v[e] + b, 0.f));
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- conv1 (Cin = 1) ----------
+// x: (N, 96, 64) log-mel examples; w: (64, 1, 3, 3) f32 as stored by the reference; out: pooled
+// NHWC (N, 48, 32, 64). One lane = one pooled pixel x all 64 channels; weights are wave-uniform
+// (scalar loads), the 4x4 input patch lives in registers.
+template <typename TIN, typename T>
+__global__ __launch_bounds__(256) void conv1_kernel(const TIN* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, T* __restrict__ out,
+                                                    int64_t n_pix) {
+    const int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= n_pix) return;
+    const int px = int(idx & 31), py = int((idx >> 5) % 48);
+    const int64_t n = idx / (48 * 32);
+    float patch[4][4];
+    _Pragma("unroll") for (int a = 0; a < 4; ++a)
+        _Pragma("unroll") for (int b = 0; b < 4; ++b) {
+            const int iy = 2 * py - 1 + a, ix = 2 * px - 1 + b;
+            patch[a][b] = (iy >= 0 && iy < 96 && ix >= 0 && ix < 64) ? load_elem<TIN>(x + (n * 96 + iy) * 64 + ix) : 0.f;
+        }
+    T* o = out + idx * 64;
+    for (int cg = 0; cg < 8; ++cg) {
+        float res[8];
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) {
+            const int ch = cg * 8 + c;
+            float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+            _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)
+                _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {
+                    const float wv = w[ch * 9 + ky * 3 + kx];
+                    a00 = fmaf(patch[ky][kx], wv, a00);
+                    a01 = fmaf(patch[ky][kx + 1], wv, a01);
+                    a10 = fmaf(patch[ky + 1][kx], wv, a10);
+                    a11 = fmaf(patch[ky + 1][kx + 1], wv, a11);
+                }
+            res[c] = fmaxf(fmaxf(fmaxf(a00, a01), fmaxf(a10, a11)) + bias[ch], 0.f);
+        }
+        if constexpr (sizeof(T) == 2) {
+            u32x4 pk;
+            pk.x = f2bf(res[0]) | (uint32_t(f2bf(res[1])) << 16);
+            pk.y = f2bf(res[2]) | (uint32_t(f2bf(res[3])) << 16);
+            pk.z = f2bf(res[4]) | (uint32_t(f2bf(res[5])) << 16);
+            pk.w = f2bf(res[6]) | (uint32_t(f2bf(res[7])) << 16);
+            *reinterpret_cast<u32x4*>(o + cg * 8) = pk;
+        } else {
+            *reinterpret_cast<f32x4*>(o + cg * 8) = f32x4{res[0], res[1], res[2], res[3]};
+            *reinterpret_cast<f32x4*>(o + cg * 8 + 4) = f32x4{res[4], res[5], res[6], res[7]};
+        }
+    }
+}
+
+// ------------------------------------------------------------- weight re-layout ------------
+// (Cout, Cin, 3, 3) f32 (state_dict layout, vggish.py:113) -> (Cout, 9, Cin) in the compute type
+template <typename T>
+__global__ void repack_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin) {
+    const int64_t total = int64_t(cout) * 9 * cin;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+        const int c = int(i % cin);
+        const int tap = int((i / cin) % 9);
+        const int o = int(i / (int64_t(cin) * 9));
+        store_elem<T>(out + i, w[(int64_t(o) * cin + c) * 9 + tap]);
+    }
+}
+
+template <typename T>
+__global__ void convert_kernel(const float* __restrict__ in, T* __restrict__ out, int64_t n) {
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+        store_elem<T>(out + i, in[i]);
+}
+
+__global__ void widen_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, int64_t n) {
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+        out[i] = bf2f(in[i].bits);
+}
+
+template <typename C>
+int launch_conv(const void* in, const void* w, const float* bias, void* out, int64_t n_img, hipStream_t s) {
+    using T = typename C::elem;
+    auto kern = conv3x3_kernel<C>;
+    MLA_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   C::LDS_BYTES));
+    const int64_t tiles = ((n_img + C::IMGS - 1) / C::IMGS) * C::TILES_Y;
+    MLA_REQUIRE(tiles <= 0x7fffffff, MLA_E_SHAPE, "too many tiles");
+    hipLaunchKernelGGL(kern, dim3(unsigned(tiles), C::COUT / C::BN), dim3(kThreads), C::LDS_BYTES, s,
+                       static_cast<const T*>(in), static_cast<const T*>(w), bias, static_cast<T*>(out), int(n_img));
+    MLA_LAUNCH_OK("conv3x3_kernel");
+    return MLA_OK;
+}
+
+template <typename T>
+int conv_layer(int layer, const void* in, const void* w, const float* bias, void* out, int64_t n, hipStream_t s) {
+    switch (layer) {                                     //        Cin Cout  H   W  pool NS
+        case 2: return launch_conv<Cfg<T, 64, 128, 48, 32, true, 2>>(in, w, bias, out, n, s);
+        case 3: return launch_conv<Cfg<T, 128, 256, 24, 16, false, 4>>(in, w, bias, out, n, s);
+        case 4: return launch_conv<Cfg<T, 256, 256, 24, 16, true, 4>>(in, w, bias, out, n, s);
+        case 5: return launch_conv<Cfg<T, 256, 512, 12, 8, false, 4>>(in, w, bias, out, n, s);
+        case 6: return launch_conv<Cfg<T, 512, 512, 12, 8, true, 4>>(in, w, bias, out, n, s);
+    }
+    return mla::fail(MLA_E_SHAPE, "conv layer %d is not one of VGGish conv2..conv6", layer);
+}
+
+}  // namespace
+
+extern "C" int mla_conv_repack_weights(const float* w_oihw, int64_t cout, int64_t cin, void* out, int dtype,
+                                       mla_stream_t stream) {
+    MLA_REQUIRE(w_oihw && out && cout > 0 && cin > 0, MLA_E_ARG, "bad repack arguments");
+    MLA_REQUIRE(dtype == MLA_F32 || dtype == MLA_BF16, MLA_E_DTYPE, "dtype %d", dtype);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t total = cout * 9 * cin;
+    const unsigned grid = unsigned((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (dtype == MLA_F32)
+        hipLaunchKernelGGL(repack_kernel<float>, dim3(grid), dim3(256), 0, s, w_oihw, static_cast<float*>(out), int(cout), int(cin));
+    else
+        hipLaunchKernelGGL(repack_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, w_oihw, static_cast<bf16_t*>(out), int(cout), int(cin));
+    MLA_LAUNCH_OK("repack_kernel");
+    return MLA_OK;
+}
+
+extern "C" int mla_convert_f32(const float* in, void* out, int64_t n, int dtype, mla_stream_t stream) {
+    MLA_REQUIRE(in && out && n >= 0, MLA_E_ARG, "bad convert arguments");
+    MLA_REQUIRE(dtype == MLA_BF16, MLA_E_DTYPE, "convert target must be bf16 (got %d)", dtype);
+    if (n == 0) return MLA_OK;
+    const unsigned grid = unsigned((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(convert_kernel<bf16_t>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), in,
+                       static_cast<bf16_t*>(out), n);
+    MLA_LAUNCH_OK("convert_kernel");
+    return MLA_OK;
+}
+
+extern "C" int mla_convert_bf16_to_f32(const void* in, float* out, int64_t n, mla_stream_t stream) {
+    MLA_REQUIRE(in && out && n >= 0, MLA_E_ARG, "bad convert arguments");
+    if (n == 0) return MLA_OK;
+    const unsigned grid = unsigned((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(widen_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(in), out, n);
+    MLA_LAUNCH_OK("widen_kernel");
+    return MLA_OK;
+}
+
+extern "C" int mla_vggish_conv1(const void* x, int x_dtype, int64_t n, const float* w, const float* bias, void* out,
+                                int dtype, mla_stream_t stream) {
+    MLA_REQUIRE(n >= 0, MLA_E_ARG, "n %lld", (long long)n);
+    if (n == 0) return MLA_OK;
+    MLA_REQUIRE(x && w && bias && out && mla::aligned(out, 16), MLA_E_ARG, "null / misaligned conv1 buffers");
+    MLA_REQUIRE((x_dtype == MLA_F32 || x_dtype == MLA_BF16) && (dtype == MLA_F32 || dtype == MLA_BF16), MLA_E_DTYPE,
+                "conv1 dtypes %d -> %d", x_dtype, dtype);
+    const int64_t n_pix = n * 48 * 32;
+    const int64_t blocks = (n_pix + 255) / 256;
+    MLA_REQUIRE(blocks <= 0x7fffffff, MLA_E_SHAPE, "batch too large");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 g{unsigned(blocks)}, b{256};
+    if (x_dtype == MLA_F32 && dtype == MLA_F32)
+        hipLaunchKernelGGL((conv1_kernel<float, float>), g, b, 0, s, static_cast<const float*>(x), w, bias, static_cast<float*>(out), n_pix);
+    else if (x_dtype == MLA_F32)
+        hipLaunchKernelGGL((conv1_kernel<float, bf16_t>), g, b, 0, s, static_cast<const float*>(x), w, bias, static_cast<bf16_t*>(out), n_pix);
+    else if (dtype == MLA_F32)
+        hipLaunchKernelGGL((conv1_kernel<bf16_t, float>), g, b, 0, s, static_cast<const bf16_t*>(x), w, bias, static_cast<float*>(out), n_pix);
+    else
+        hipLaunchKernelGGL((conv1_kernel<bf16_t, bf16_t>), g, b, 0, s, static_cast<const bf16_t*>(x), w, bias, static_cast<bf16_t*>(out), n_pix);
+    MLA_LAUNCH_OK("conv1_kernel");
+    return MLA_OK;
+}
+
+extern "C" int mla_vggish_conv(int layer, const void* in, const void* w_repacked, const float* bias, void* out,
+                               int64_t n, int dtype, mla_stream_t stream) {
+    MLA_REQUIRE(n >= 0, MLA_E_ARG, "n %lld", (long long)n);
+    if (n == 0) return MLA_OK;
+    MLA_REQUIRE(in && w_repacked && bias && out, MLA_E_ARG, "null conv buffers");
+    MLA_REQUIRE(mla::aligned(in, 16) && mla::aligned(w_repacked, 16) && mla::aligned(out, 4), MLA_E_ARG, "conv buffers must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == MLA_F32) return conv_layer<float>(layer, in, w_repacked, bias, out, n, s);
+    if (dtype == MLA_BF16) return conv_layer<bf16_t>(layer, in, w_repacked, bias, out, n, s);
+    return mla::fail(MLA_E_DTYPE, "conv dtype %d", dtype);
+}

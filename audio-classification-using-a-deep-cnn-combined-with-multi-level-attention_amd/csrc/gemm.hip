@@ -1,0 +1,151 @@
+// gemm.hip -- out[M, N] = act(A[M, K] . W[N, K]^T + bias[N]) on the matrix cores, for every
+// torch.nn.Linear on the hot path: VGG.embeddings (vggish.py:13-19: 12288->4096->4096->128,
+// each followed by ReLU) and the MLA head's fc / fcv layers (model.py:207-210, :230, :255).
+// Both operands are K-contiguous exactly as PyTorch stores them (activations row-major,
+// Linear.weight = [out, in]), so no transposition is ever materialised.
+//
+// Same tile machinery as conv.hip (mma_core.h): 512 threads = 2 (M) x 4 (N) waves, tile
+// 128 x (64 NS), 128-byte K chunks (64 bf16 / 32 f32) double-buffered in LDS with the next
+// chunk's global loads in flight behind the MFMAs; M / N / K tails are zero-filled on load and
+// masked on store. bf16 uses v_mfma_f32_16x16x32_bf16, f32 the exact v_mfma_f32_16x16x4_f32.
+#include "common.h"
+#include "mma_core.h"
+
+namespace {
+
+using namespace mma;
+
+constexpr int kThreads = 512, kMS = 4, kBM = 128;
+
+template <typename T, typename TO, int NS, bool RELU>
+__global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__ A, int64_t lda,
+                                                            const T* __restrict__ W, int64_t ldw,
+                                                            const float* __restrict__ bias, TO* __restrict__ out,
+                                                            int64_t ldo, int M, int N, int K) {
+    constexpr int PER = Elem<T>::kPerChunk, KC = Elem<T>::kPerRow;
+    constexpr int BN = 4 * NS * 16;
+    constexpr int A_BYTES = kBM * kRowBytes, B_BYTES = BN * kRowBytes;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;
+    char* sB = smem + 2 * A_BYTES;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.x * kBM, n0 = blockIdx.y * BN;
+    const int abase = (wm * kMS * 16 + r) * kRowBytes + 16 * (q ^ ((r >> 1) & 7));
+    const int bbase = (wn * NS * 16 + r) * kRowBytes + 16 * (q ^ ((r >> 1) & 7));
+
+    f32x4 acc[kMS][NS];
+    _Pragma("unroll") for (int i = 0; i < kMS; ++i)
+        _Pragma("unroll") for (int j = 0; j < NS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 areg[2], breg[NS];
+    auto gload = [&](int s) {
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {
+            const int piece = t + kThreads * p, row = piece >> 3, ch = piece & 7;
+            const int k = s * KC + ch * PER;
+            areg[p] = zero16();
+            if (m0 + row < M && k < K) areg[p] = *reinterpret_cast<const u32x4*>(A + size_t(m0 + row) * lda + k);
+        }
+        _Pragma("unroll") for (int p = 0; p < NS; ++p) {
+            const int piece = t + kThreads * p, n = piece >> 3, ch = piece & 7;
+            const int k = s * KC + ch * PER;
+            breg[p] = zero16();
+            if (n0 + n < N && k < K) breg[p] = *reinterpret_cast<const u32x4*>(W + size_t(n0 + n) * ldw + k);
+        }
+    };
+    auto lwrite = [&](int buf) {
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {
+            const int piece = t + kThreads * p;
+            lds_write16(sA, buf * A_BYTES + tile_off(piece >> 3, piece & 7), areg[p]);
+        }
+        _Pragma("unroll") for (int p = 0; p < NS; ++p) {
+            const int piece = t + kThreads * p;
+            lds_write16(sB, buf * B_BYTES + tile_off(piece >> 3, piece & 7), breg[p]);
+        }
+    };
+
+    const int stages = (K + KC - 1) / KC;
+    gload(0);
+    lwrite(0);
+    __syncthreads();
+    for (int s = 0; s < stages; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < stages) gload(s + 1);
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {
+            u32x4 af[kMS], bf[NS];
+            _Pragma("unroll") for (int i = 0; i < kMS; ++i)
+                af[i] = lds_read16(sA, buf * A_BYTES + (abase ^ (ks << 6)) + i * 16 * kRowBytes);
+            _Pragma("unroll") for (int j = 0; j < NS; ++j)
+                bf[j] = lds_read16(sB, buf * B_BYTES + (bbase ^ (ks << 6)) + j * 16 * kRowBytes);
+            _Pragma("unroll") for (int i = 0; i < kMS; ++i)
+                _Pragma("unroll") for (int j = 0; j < NS; ++j) mma_step<T>(af[i], bf[j], acc[i][j]);
+        }
+        if (s + 1 < stages) lwrite(buf ^ 1);   // the other buffer was last read before the previous barrier
+        __syncthreads();
+    }
+
+    _Pragma("unroll") for (int j = 0; j < NS; ++j) {
+        const int n = n0 + (wn * NS + j) * 16 + r;
+        if (n >= N) continue;
+        const float b = bias ? bias[n] : 0.f;
+        _Pragma("unroll") for (int i = 0; i < kMS; ++i) {
+            const float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {
+                const int m = m0 + (wm * kMS + i) * 16 + 4 * q + e;
+                if (m < M) {
+                    float y = v[e] + b;
+                    if (RELU) y = fmaxf(y, 0.f);
+                    store_elem<TO>(out + size_t(m) * ldo + n, y);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, typename TO, int NS, bool RELU>
+int launch(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* out, int64_t ldo,
+           int64_t M, int64_t N, int64_t K, hipStream_t s) {
+    constexpr int BN = 4 * NS * 16;
+    constexpr int lds = 2 * (kBM + BN) * kRowBytes;
+    auto kern = gemm_kernel<T, TO, NS, RELU>;
+    MLA_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const dim3 grid{unsigned((M + kBM - 1) / kBM), unsigned((N + BN - 1) / BN)};
+    hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, static_cast<const T*>(a), lda, static_cast<const T*>(w), ldw,
+                       bias, static_cast<TO*>(out), ldo, int(M), int(N), int(K));
+    MLA_LAUNCH_OK("gemm_kernel");
+    return MLA_OK;
+}
+
+template <typename T, typename TO>
+int dispatch(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* out, int64_t ldo,
+             int64_t M, int64_t N, int64_t K, bool relu, hipStream_t s) {
+    const bool wide = N > 128 && (N % 256 == 0 || N % 256 > 128);     // 256-wide tiles unless they waste > half a tile
+    if (wide) return relu ? launch<T, TO, 4, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s)
+                          : launch<T, TO, 4, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s);
+    return relu ? launch<T, TO, 2, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s)
+                : launch<T, TO, 2, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s);
+}
+
+}  // namespace
+
+extern "C" int mla_linear(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* out,
+                          int64_t ldo, int64_t M, int64_t N, int64_t K, int dtype, int out_dtype, int relu,
+                          mla_stream_t stream) {
+    MLA_REQUIRE(M >= 0 && N > 0 && K > 0, MLA_E_ARG, "bad GEMM shape %lld x %lld x %lld", (long long)M, (long long)N, (long long)K);
+    if (M == 0) return MLA_OK;
+    MLA_REQUIRE(a && w && out, MLA_E_ARG, "null GEMM operand");
+    MLA_REQUIRE(dtype == MLA_F32 || dtype == MLA_BF16, MLA_E_DTYPE, "GEMM dtype %d", dtype);
+    MLA_REQUIRE(out_dtype == MLA_F32 || (out_dtype == MLA_BF16 && dtype == MLA_BF16), MLA_E_DTYPE,
+                "GEMM out dtype %d for compute dtype %d", out_dtype, dtype);
+    const int per = dtype == MLA_F32 ? 4 : 8;
+    MLA_REQUIRE(K % per == 0 && lda % per == 0 && ldw % per == 0 && lda >= K && ldw >= K && ldo >= N, MLA_E_SHAPE,
+                "K / lda / ldw must be multiples of %d elements (16-byte rows): K %lld lda %lld ldw %lld ldo %lld", per,
+                (long long)K, (long long)lda, (long long)ldw, (long long)ldo);
+    MLA_REQUIRE(mla::aligned(a, 16) && mla::aligned(w, 16), MLA_E_ARG, "GEMM operands must be 16-byte aligned");
+    MLA_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), MLA_E_SHAPE, "GEMM dimension overflow");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == MLA_F32) return dispatch<float, float>(a, lda, w, ldw, bias, out, ldo, M, N, K, relu != 0, s);
+    if (out_dtype == MLA_F32) return dispatch<mma::bf16_t, float>(a, lda, w, ldw, bias, out, ldo, M, N, K, relu != 0, s);
+    return dispatch<mma::bf16_t, mma::bf16_t>(a, lda, w, ldw, bias, out, ldo, M, N, K, relu != 0, s);
+}

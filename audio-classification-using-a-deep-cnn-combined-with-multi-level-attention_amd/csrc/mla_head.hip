@@ -1,0 +1,271 @@
+// mla_head.hip -- the small, HBM/launch-bound pieces of the multi-level-attention head
+// (reference: model.py:200-269). The Linear layers go through gemm.hip; here:
+//
+//   bn_stats / bn_apply   torch.nn.BatchNorm1d as the reference uses it (model.py:205, :213,
+//                         :232-233, :256). On a (B, T, F) tensor BatchNorm1d(T) takes the TIME
+//                         SLOT as channel: statistics over (batch, feature) per t ("row-periodic"
+//                         mode on the flattened (B*T, F) matrix, channel = row % T); on the (B, K)
+//                         logits BatchNorm1d(K) is per column. Train mode: biased batch variance
+//                         for normalisation, unbiased for the running update (momentum 0.1).
+//                         bn_apply fuses the affine, ReLU / sigmoid and the dropout mask.
+//   attention_pool        model.py:237-240: att = softmax_K(BNv(z)), cla = sigmoid(BNf(z)) on the
+//                         SAME z = fcv(h) (the reference never uses fcf), att normalised over T,
+//                         y = sum_T cla * att. 16 lanes per bag, shuffle reductions.
+//   linear_small          model.py:255/:268 fc (L*K -> K): too small / unaligned for the MFMA GEMM.
+//
+// Reductions are deterministic: per-block double-precision partials in a caller-provided
+// workspace, combined in fixed order by a single finishing block.
+#include "common.h"
+
+namespace {
+
+constexpr int kStatBlocks = 512;        // upper bound on partial-producing blocks
+constexpr int kMaxChannels = 64;
+
+__device__ __forceinline__ double wave_sum(double v) {
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// mode 0: channel = row % period; one wave per row, lanes stride the columns
+__global__ __launch_bounds__(256) void stats_rows_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ldx,
+                                                         int period, double* __restrict__ partial) {
+    __shared__ double part[4][kMaxChannels][2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 4 * kMaxChannels * 2; i += 256) (&part[0][0][0])[i] = 0.0;
+    __syncthreads();
+    const int64_t per_block = ((rows + gridDim.x - 1) / gridDim.x + period - 1) / period * period;
+    const int64_t r0 = int64_t(blockIdx.x) * per_block;
+    const int64_t r1 = r0 + per_block < rows ? r0 + per_block : rows;
+    for (int64_t r = r0 + wave; r < r1; r += 4) {
+        const float* row = x + r * ldx;
+        double s = 0.0, ss = 0.0;
+        for (int c = lane; c < cols; c += 64) {
+            const double v = row[c];
+            s += v;
+            ss += v * v;
+        }
+        s = wave_sum(s);
+        ss = wave_sum(ss);
+        if (lane == 0) {
+            const int ch = int(r % period);
+            part[wave][ch][0] += s;
+            part[wave][ch][1] += ss;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < period) {
+        double s = 0.0, ss = 0.0;
+        for (int w = 0; w < 4; ++w) { s += part[w][threadIdx.x][0]; ss += part[w][threadIdx.x][1]; }
+        partial[(int64_t(blockIdx.x) * period + threadIdx.x) * 2] = s;
+        partial[(int64_t(blockIdx.x) * period + threadIdx.x) * 2 + 1] = ss;
+    }
+}
+
+// mode 1: channel = column (cols <= 64); thread (g, c) walks rows g, g + G, ...
+__global__ __launch_bounds__(256) void stats_cols_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ldx,
+                                                         double* __restrict__ partial) {
+    __shared__ double part[256][2];
+    const int groups = 256 / cols, g = threadIdx.x / cols, c = threadIdx.x % cols;
+    double s = 0.0, ss = 0.0;
+    if (g < groups) {
+        const int64_t per_block = (rows + gridDim.x - 1) / gridDim.x;
+        const int64_t r0 = int64_t(blockIdx.x) * per_block;
+        const int64_t r1 = r0 + per_block < rows ? r0 + per_block : rows;
+        for (int64_t r = r0 + g; r < r1; r += groups) {
+            const double v = x[r * ldx + c];
+            s += v;
+            ss += v * v;
+        }
+    }
+    part[threadIdx.x][0] = s;
+    part[threadIdx.x][1] = ss;
+    __syncthreads();
+    if (threadIdx.x < cols) {
+        double a = 0.0, b = 0.0;
+        for (int gg = 0; gg < groups; ++gg) { a += part[gg * cols + threadIdx.x][0]; b += part[gg * cols + threadIdx.x][1]; }
+        partial[(int64_t(blockIdx.x) * cols + threadIdx.x) * 2] = a;
+        partial[(int64_t(blockIdx.x) * cols + threadIdx.x) * 2 + 1] = b;
+    }
+}
+
+__global__ void stats_finish_kernel(const double* __restrict__ partial, int blocks, int channels, double count,
+                                    float* __restrict__ mean, float* __restrict__ var, float* __restrict__ run_mean,
+                                    float* __restrict__ run_var, float momentum) {
+    const int c = threadIdx.x;
+    if (c >= channels) return;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < blocks; ++b) { s += partial[(int64_t(b) * channels + c) * 2]; ss += partial[(int64_t(b) * channels + c) * 2 + 1]; }
+    const double m = s / count;
+    double v = ss / count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean[c] = float(m);
+    var[c] = float(v);
+    if (run_mean && momentum >= 0.f) {
+        const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
+        run_mean[c] = float((1.0 - momentum) * run_mean[c] + momentum * m);
+        run_var[c] = float((1.0 - momentum) * run_var[c] + momentum * unbiased);
+    }
+}
+
+__device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + __expf(-v)); }
+
+// y = act((x - mean[c]) * rsqrt(var[c] + eps) * gamma[c] + beta[c]) * keep * drop_scale
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
+                                                       int64_t ldy, int64_t rows, int cols, int period,
+                                                       const float* __restrict__ mean, const float* __restrict__ var,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, int act, const uint8_t* __restrict__ keep,
+                                                       float drop_scale) {
+    const int64_t total = rows * cols;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < total; i += int64_t(gridDim.x) * 256) {
+        const int64_t r = i / cols;
+        const int c = int(i - r * cols);
+        const int ch = MODE == 0 ? int(r % period) : c;
+        const float inv = 1.0f / sqrtf(var[ch] + eps);
+        float v = (x[r * ldx + c] - mean[ch]) * inv * gamma[ch] + beta[ch];
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = sigmoidf(v);
+        if (keep) v = keep[i] ? v * drop_scale : 0.f;
+        y[r * ldy + c] = v;
+    }
+}
+
+struct BnParams { const float *mean, *var, *gamma, *beta; };
+
+// 16 lanes per bag; lane t < T owns time slot t, all K classes in registers (K <= 16)
+template <int KMAX>
+__global__ __launch_bounds__(256) void attention_pool_kernel(const float* __restrict__ z, int64_t bags, int T, int K,
+                                                             BnParams nv, BnParams nf, float eps, float* __restrict__ y,
+                                                             int64_t ldy, float* __restrict__ att_out,
+                                                             float* __restrict__ cla_out) {
+    const int t = threadIdx.x & 15;
+    const int64_t bag = int64_t(blockIdx.x) * 16 + (threadIdx.x >> 4);
+    const bool live = bag < bags && t < T;
+    float att[KMAX], cla[KMAX];
+    if (live) {
+        const float* row = z + (bag * T + t) * K;
+        const float iv = 1.0f / sqrtf(nv.var[t] + eps), jf = 1.0f / sqrtf(nf.var[t] + eps);
+        float mx = -3.0e38f;
+        _Pragma("unroll") for (int k = 0; k < KMAX; ++k)
+            if (k < K) {
+                const float v = row[k];
+                att[k] = (v - nv.mean[t]) * iv * nv.gamma[t] + nv.beta[t];
+                cla[k] = sigmoidf((v - nf.mean[t]) * jf * nf.gamma[t] + nf.beta[t]);
+                mx = fmaxf(mx, att[k]);
+            }
+        float den = 0.f;
+        _Pragma("unroll") for (int k = 0; k < KMAX; ++k)
+            if (k < K) { att[k] = __expf(att[k] - mx); den += att[k]; }
+        const float inv = 1.0f / den;
+        _Pragma("unroll") for (int k = 0; k < KMAX; ++k)
+            if (k < K) {
+                att[k] *= inv;
+                if (att_out) att_out[(bag * T + t) * K + k] = att[k];
+                if (cla_out) cla_out[(bag * T + t) * K + k] = cla[k];
+            }
+    } else {
+        _Pragma("unroll") for (int k = 0; k < KMAX; ++k) { att[k] = 0.f; cla[k] = 0.f; }
+    }
+    _Pragma("unroll") for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {                                   // K is block-uniform: shuffles stay convergent
+            float s = att[k];
+            _Pragma("unroll") for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+            float num = live ? cla[k] * (att[k] / s) : 0.f;     // model.py:239-240: cla * (att / sum_T att)
+            _Pragma("unroll") for (int o = 8; o > 0; o >>= 1) num += __shfl_xor(num, o, 16);
+            if (t == 0 && bag < bags) y[bag * ldy + k] = num;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ a, int64_t lda,
+                                                           const float* __restrict__ w, int64_t ldw,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           int64_t ldo, int64_t M, int N, int K) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= M * N) return;
+    const int64_t m = i / N;
+    const int n = int(i - m * N);
+    float acc = bias ? bias[n] : 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(a[m * lda + k], w[int64_t(n) * ldw + k], acc);
+    out[m * ldo + n] = acc;
+}
+
+}  // namespace
+
+extern "C" int64_t mla_bn_stats_workspace_bytes(void) { return int64_t(kStatBlocks) * kMaxChannels * 2 * sizeof(double); }
+
+extern "C" int mla_bn_stats(const float* x, int64_t rows, int64_t cols, int64_t ldx, int mode, int period, void* workspace,
+                            float* mean, float* var_biased, float* running_mean, float* running_var, float momentum,
+                            mla_stream_t stream) {
+    MLA_REQUIRE(x && workspace && mean && var_biased && rows > 0 && cols > 0 && ldx >= cols, MLA_E_ARG, "bad bn_stats arguments");
+    MLA_REQUIRE(mode == 0 || mode == 1, MLA_E_ARG, "bn_stats mode %d", mode);
+    const int channels = mode == 0 ? period : int(cols);
+    MLA_REQUIRE(channels >= 1 && channels <= kMaxChannels, MLA_E_SHAPE, "bn_stats supports 1..%d channels (got %d)", kMaxChannels, channels);
+    MLA_REQUIRE(mode == 1 || rows % period == 0, MLA_E_SHAPE, "rows %lld not a multiple of period %d", (long long)rows, period);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* partial = static_cast<double*>(workspace);
+    int blocks;
+    double count;
+    if (mode == 0) {
+        const int64_t groups = rows / period;
+        blocks = int(groups < kStatBlocks ? groups : kStatBlocks);
+        count = double(groups) * double(cols);
+        hipLaunchKernelGGL(stats_rows_kernel, dim3(blocks), dim3(256), 0, s, x, rows, int(cols), ldx, period, partial);
+        // blocks whose row range is empty still write zero partials (per_block rounding): all `blocks` slots are valid
+    } else {
+        blocks = int((rows + 63) / 64 < kStatBlocks ? (rows + 63) / 64 : kStatBlocks);
+        count = double(rows);
+        hipLaunchKernelGGL(stats_cols_kernel, dim3(blocks), dim3(256), 0, s, x, rows, int(cols), ldx, partial);
+    }
+    MLA_LAUNCH_OK("bn stats");
+    hipLaunchKernelGGL(stats_finish_kernel, dim3(1), dim3(64), 0, s, partial, blocks, channels, count, mean, var_biased,
+                       running_mean, running_var, momentum);
+    MLA_LAUNCH_OK("bn stats finish");
+    return MLA_OK;
+}
+
+extern "C" int mla_bn_apply(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t cols, int mode,
+                            int period, const float* mean, const float* var, const float* gamma, const float* beta,
+                            float eps, int act, const uint8_t* keep_mask, float drop_scale, mla_stream_t stream) {
+    MLA_REQUIRE(x && y && mean && var && gamma && beta && rows >= 0 && cols > 0, MLA_E_ARG, "bad bn_apply arguments");
+    MLA_REQUIRE((mode == 0 && period >= 1) || mode == 1, MLA_E_ARG, "bn_apply mode %d period %d", mode, period);
+    MLA_REQUIRE(act >= 0 && act <= 2, MLA_E_ARG, "bn_apply act %d", act);
+    if (rows == 0) return MLA_OK;
+    const int64_t total = rows * cols;
+    const unsigned grid = unsigned((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (mode == 0)
+        hipLaunchKernelGGL(bn_apply_kernel<0>, dim3(grid), dim3(256), 0, s, x, ldx, y, ldy, rows, int(cols), period, mean, var,
+                           gamma, beta, eps, act, keep_mask, drop_scale);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(grid), dim3(256), 0, s, x, ldx, y, ldy, rows, int(cols), period, mean, var,
+                           gamma, beta, eps, act, keep_mask, drop_scale);
+    MLA_LAUNCH_OK("bn_apply");
+    return MLA_OK;
+}
+
+extern "C" int mla_attention_pool(const float* z, int64_t bags, int T, int K, const float* v_mean, const float* v_var,
+                                  const float* v_gamma, const float* v_beta, const float* f_mean, const float* f_var,
+                                  const float* f_gamma, const float* f_beta, float eps, float* y, int64_t ldy,
+                                  float* att_out, float* cla_out, mla_stream_t stream) {
+    MLA_REQUIRE(z && y && v_mean && v_var && v_gamma && v_beta && f_mean && f_var && f_gamma && f_beta, MLA_E_ARG, "null attention_pool argument");
+    MLA_REQUIRE(T >= 1 && T <= 16 && K >= 1 && K <= 16 && ldy >= K, MLA_E_SHAPE, "attention_pool supports T, K <= 16 (got %d, %d)", T, K);
+    if (bags == 0) return MLA_OK;
+    BnParams nv{v_mean, v_var, v_gamma, v_beta}, nf{f_mean, f_var, f_gamma, f_beta};
+    hipLaunchKernelGGL(attention_pool_kernel<16>, dim3(unsigned((bags + 15) / 16)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), z, bags, T, K, nv, nf, eps, y, ldy, att_out, cla_out);
+    MLA_LAUNCH_OK("attention_pool");
+    return MLA_OK;
+}
+
+extern "C" int mla_linear_small(const float* a, int64_t lda, const float* w, int64_t ldw, const float* bias, float* out,
+                                int64_t ldo, int64_t M, int64_t N, int64_t K, mla_stream_t stream) {
+    MLA_REQUIRE(a && w && out && M >= 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldo >= N, MLA_E_ARG, "bad linear_small arguments");
+    if (M == 0) return MLA_OK;
+    hipLaunchKernelGGL(linear_small_kernel, dim3(unsigned((M * N + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a, lda, w, ldw, bias, out, ldo, M, int(N), int(K));
+    MLA_LAUNCH_OK("linear_small");
+    return MLA_OK;
+}

@@ -1,0 +1,209 @@
+"""Drop-in for the reference's ``model.py`` (vggish branch): ``Ensemble``, ``Input``, ``CNN``,
+``CnnFlatten``, ``EmbeddedMapping``, ``AttentionModule``, ``MultiLevelAttention`` and
+``set_requires_grad`` with the same constructor arguments, attribute names and ``state_dict``
+keys (model.py:14, :68, :107, :179, :202, :228, :248, :272), executed by HIP kernels.
+
+Reproduced on purpose (SURVEY.md section 7 "quirks"): ``fcv`` feeds both attention branches
+and ``fcf`` is a dead parameter (model.py:230-238); BatchNorm1d(T) treats the time slot as
+channel; the outputs are sigmoids that train.py feeds to CrossEntropyLoss; ``Input`` is a
+reshape, never a transpose (model.py:98-99). The ``resnet`` branches are outside the hot path
+ and raise.
+"""
+
+from typing import Dict, List, Union
+
+import torch
+from torch import nn
+
+from . import mla_train, ops
+from .params import *  # noqa: F401,F403  (T, H, K, DR, M_VGGISH, M_VGGISH_JB, S_VGGISH_SHAPE: model.py:9)
+from .torchvggish.vggish import Linear, VGGish
+
+
+class BatchNorm1d(nn.Module):
+    """Parameter / buffer holder with torch.nn.BatchNorm1d's names (weight, bias, running_mean,
+    running_var, num_batches_tracked), defaults eps 1e-5, momentum 0.1."""
+
+    def __init__(self, num_features):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, 1e-5, 0.1
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x):
+        raise RuntimeError("BatchNorm1d is executed by the fused HIP head of its parent module")
+
+
+class Dropout(nn.Module):
+    """nn.Dropout(p) stand-in. ``mask`` (uint8 keep-mask, 1 = keep) may be injected for
+    reproducible runs; otherwise a fresh Bernoulli(1 - p) mask is drawn per training forward."""
+
+    def __init__(self, p=0.5):
+        super().__init__()
+        self.p, self.mask = p, None
+
+    def keep_mask(self, numel, device):
+        if self.mask is not None:
+            m = self.mask.to(device=device, dtype=torch.uint8).reshape(-1).contiguous()
+            assert m.numel() == numel
+            return m
+        return torch.empty(numel, dtype=torch.uint8, device=device).bernoulli_(1.0 - self.p)
+
+    def forward(self, x):
+        raise RuntimeError("Dropout is fused into the HIP BatchNorm/ReLU kernel of its parent module")
+
+
+class Ensemble(nn.Module):
+    def __init__(self, input_conf: str, cnn_conf: Dict[str, Union[str, int]], model_conf: List[int], device,
+                 precision: str = "f32"):
+        super().__init__()
+        self.cnn_type = cnn_conf["cnn_type"]
+        self.just_bottlenecks = cnn_conf["just_bottlenecks"]
+        self.num_classes = cnn_conf["num_classes"]
+        if self.cnn_type == "vggish" and self.just_bottlenecks:
+            self.emb_input_size = M_VGGISH_JB
+        elif self.cnn_type == "vggish" and not self.just_bottlenecks:
+            self.emb_input_size = M_VGGISH
+        elif self.cnn_type == "resnet":
+            raise Exception("cnn_type 'resnet' is outside the MI355X hot path (torchvision ResNet-50); use 'vggish'.")
+        else:
+            raise Exception("CNN type is not valid.")
+        self.input = Input(input_conf=input_conf, cnn_type=self.cnn_type, device=device)
+        self.mla = MultiLevelAttention(model_conf, self.emb_input_size)
+        self.cnn = CNN(**cnn_conf, precision=precision)
+
+    def set_precision(self, precision):
+        self.cnn.set_precision(precision)
+        return self
+
+    def forward(self, x):
+        x_proc = self.input(x)
+        features = self.cnn(x_proc)
+        out = self.mla(features.reshape(-1, T, self.emb_input_size))
+        return out
+
+    def forward_waveforms(self, pcm):
+        """Fused online path of the north star: (B, n_samples) 16 kHz PCM on the device (float32
+        or int16), one bag per row with exactly T examples -> (B, K) scores. The front-end writes
+        the examples directly in the CNN's compute dtype."""
+        from . import frontend
+        dtype = torch.bfloat16 if self.cnn.precision == "bf16" else torch.float32
+        ex = frontend.waveforms_to_examples(pcm, out_dtype=dtype)
+        assert ex.shape[0] == pcm.shape[0] * T, "each waveform must yield exactly T examples"
+        features = self.cnn(ex)
+        return self.mla(features.reshape(-1, T, self.emb_input_size))
+
+
+class Input(nn.Module):
+    def __init__(self, input_conf, cnn_type, device):
+        super().__init__()
+        self.conf, self.device, self.cnn_type = input_conf, device, cnn_type
+
+    def forward(self, x):
+        if self.cnn_type == "vggish":
+            return x.reshape((-1, 1, S_VGGISH_SHAPE[0], S_VGGISH_SHAPE[1]))
+        elif self.cnn_type == "resnet":
+            raise Exception("cnn_type 'resnet' is outside the MI355X hot path.")
+        else:
+            raise Exception("CNN type is not valid.")
+
+
+class CNN(nn.Module):
+    def __init__(self, cnn_type="vggish", num_classes=10, use_pretrained=True, just_bottlenecks=False,
+                 cnn_trainable=False, first_cnn_layer_trainable=False, in_channels=3, precision="f32"):
+        super().__init__()
+        self.precision = precision
+        if cnn_type == "vggish":
+            model_urls = {"vggish": "https://github.com/harritaylor/torchvggish/releases/download/v0.1/vggish-10086976.pth"}
+            self.cnn_model = VGGish(urls=model_urls, pretrained=use_pretrained, preprocess=False, postprocess=False,
+                                    progress=True, precision=precision)
+            if not cnn_trainable:
+                set_requires_grad(self.cnn_model, False)
+            if just_bottlenecks:
+                self.cnn_model = nn.Sequential(list(self.cnn_model.children())[0], CnnFlatten(cnn_type))
+        elif cnn_type == "resnet":
+            raise Exception("cnn_type 'resnet' is outside the MI355X hot path (torchvision ResNet-50); use 'vggish'.")
+        else:
+            raise Exception("Invalid CNN model name specified.")
+
+    def set_precision(self, precision):
+        self.precision = precision
+        for m in self.cnn_model.modules():
+            if hasattr(m, "precision"):
+                m.precision = precision
+        return self
+
+    def forward(self, x):
+        x = self.cnn_model(x)
+        if x.dtype == torch.bfloat16:      # bf16 bottlenecks (just_bottlenecks=True) feed the f32 head
+            x = ops.to_f32(x.contiguous())
+        return x
+
+
+class CnnFlatten(nn.Module):
+    def __init__(self, cnn_type):
+        super().__init__()
+        self.cnn_type = cnn_type
+
+    def forward(self, x):
+        if self.cnn_type == "vggish":
+            x = torch.transpose(x, 1, 3)
+            x = torch.transpose(x, 1, 2)
+            x = x.contiguous()           # no copy: VGGFeatures returns an NCHW view of NHWC memory
+            x = x.view(x.size(0), -1)
+        else:
+            raise Exception("Invalid CNN model name specified.")
+        return x
+
+
+class EmbeddedMapping(nn.Module):
+    def __init__(self, n_fc, is_first, emb_input_size):
+        super().__init__()
+        self.n_fc = n_fc
+        self.norm0 = BatchNorm1d(T)
+        if is_first:
+            self.fc = nn.ModuleList([Linear(emb_input_size, H)] + [Linear(H, H) for _ in range(n_fc - 1)])
+        else:
+            self.fc = nn.ModuleList([Linear(H, H) for _ in range(n_fc)])
+        self.dropouts = nn.ModuleList([Dropout(p=DR) for _ in range(n_fc)])
+        self.norms = nn.ModuleList([BatchNorm1d(T) for _ in range(n_fc)])
+
+    def forward(self, x):
+        return mla_train.embedded_mapping_forward(self, x, None)
+
+
+class AttentionModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.fcv = Linear(H, K)
+        self.fcf = Linear(H, K)          # never used by forward (model.py:237-238); kept for the state_dict
+        self.normv = BatchNorm1d(T)
+        self.normf = BatchNorm1d(T)
+
+    def forward(self, h):
+        y = torch.empty((h.shape[0], K), dtype=torch.float32, device=h.device)
+        mla_train.attention_forward(self, h, y, None)
+        return y
+
+
+class MultiLevelAttention(nn.Module):
+    def __init__(self, model_conf, emb_input_size):
+        super().__init__()
+        self.model = model_conf
+        self.embedded_mappings = nn.ModuleList(
+            [EmbeddedMapping(model_conf[0], is_first=True, emb_input_size=emb_input_size)] +
+            [EmbeddedMapping(n_layers, is_first=False, emb_input_size=emb_input_size) for n_layers in model_conf[1:]])
+        self.attention_modules = nn.ModuleList([AttentionModule() for _ in model_conf])
+        self.fc = Linear(len(model_conf) * K, K)
+        self.norm = BatchNorm1d(K)
+
+    def forward(self, x):
+        return mla_train.mla_apply(self, x)
+
+
+def set_requires_grad(model, value):
+    for param in model.parameters():
+        param.requires_grad = value

@@ -79,6 +79,80 @@ int mla_logmel_examples(const void* pcm, int pcm_dtype, int64_t n_wave, int64_t 
                         int64_t wave_stride, const float* tables, void* out, int out_dtype,
                         mla_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * VGGish feature stack: torchvggish/vggish.py:108-118 (make_layers) applied at :22.
+ * Activations are NHWC (N, H, W, C) in the compute dtype (MLA_BF16 or MLA_F32); this
+ * makes the reference's NCHW->NHWC flatten (vggish.py:26-29, model.py:190-193) a no-op.
+ * ---------------------------------------------------------------------------------- */
+
+/* nn.Conv2d weight (Cout, Cin, 3, 3) f32 (state_dict layout) -> (Cout, 9, Cin) in `dtype`,
+ * the K-contiguous layout the implicit-GEMM kernels stream. */
+int mla_conv_repack_weights(const float* w_oihw, int64_t cout, int64_t cin, void* out, int dtype,
+                            mla_stream_t stream);
+/* f32 -> bf16 copy (nn.Linear weights for the bf16 GEMMs). */
+int mla_convert_f32(const float* in, void* out, int64_t n, int dtype, mla_stream_t stream);
+/* bf16 -> f32 copy (bf16 conv bottlenecks feeding the f32 MLA head, model.py:162-167 path). */
+int mla_convert_bf16_to_f32(const void* in, float* out, int64_t n, mla_stream_t stream);
+
+/* features[0..2]: Conv2d(1, 64, 3, pad 1) + ReLU + MaxPool2d(2, 2) fused.
+ * x: (n, 96, 64) examples (x_dtype MLA_F32 | MLA_BF16); w: (64, 1, 3, 3) f32; bias (64) f32;
+ * out: (n, 48, 32, 64) NHWC in `dtype`. */
+int mla_vggish_conv1(const void* x, int x_dtype, int64_t n, const float* w, const float* bias, void* out,
+                     int dtype, mla_stream_t stream);
+
+/* conv `layer` in 2..6 = features[3], [6], [8], [11], [13], each fused with its ReLU and,
+ * for layers 2, 4 and 6, with the MaxPool2d(2, 2) that follows it:
+ *   2: (n,48,32, 64) -> (n,24,16,128)     3: (n,24,16,128) -> (n,24,16,256)
+ *   4: (n,24,16,256) -> (n,12, 8,256)     5: (n,12, 8,256) -> (n,12, 8,512)
+ *   6: (n,12, 8,512) -> (n, 6, 4,512)
+ * in / out / w_repacked (from mla_conv_repack_weights) in `dtype`; bias f32. */
+int mla_vggish_conv(int layer, const void* in, const void* w_repacked, const float* bias, void* out,
+                    int64_t n, int dtype, mla_stream_t stream);
+
+/* torch.nn.Linear (+ optional ReLU): out[M, N] = act(a[M, K] . w[N, K]^T + bias[N]).
+ * VGG.embeddings (vggish.py:13-19) and the MLA fc / fcv layers (model.py:207-210, :230).
+ * a, w in `dtype` with leading dimensions lda, ldw (elements, 16-byte multiples); out in
+ * out_dtype (MLA_F32, or MLA_BF16 when dtype is MLA_BF16); bias f32 or NULL. */
+int mla_linear(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* out,
+               int64_t ldo, int64_t M, int64_t N, int64_t K, int dtype, int out_dtype, int relu,
+               mla_stream_t stream);
+/* Same contract in f32 without alignment requirements, for tiny layers (model.py:255 fc). */
+int mla_linear_small(const float* a, int64_t lda, const float* w, int64_t ldw, const float* bias,
+                     float* out, int64_t ldo, int64_t M, int64_t N, int64_t K, mla_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Multi-level attention head: model.py:200-269 (f32 throughout)
+ * ---------------------------------------------------------------------------------- */
+
+/* torch.nn.BatchNorm1d batch statistics (train mode). x: (rows, cols) f32, leading dim ldx.
+ *   mode 0: channel = row % period  -- BatchNorm1d(T) on a (B, T, F) tensor flattened to
+ *           (B*T, F) (model.py:205, :213, :232-233): statistics over (batch, feature) per slot;
+ *   mode 1: channel = column        -- BatchNorm1d(K) on (B, K) (model.py:256).
+ * Writes mean and BIASED variance (what normalisation uses); if running_mean/var are non-NULL
+ * and momentum >= 0 they are updated in place with the UNBIASED variance, as torch does.
+ * workspace: mla_bn_stats_workspace_bytes() bytes of device memory. Deterministic. */
+int64_t mla_bn_stats_workspace_bytes(void);
+int mla_bn_stats(const float* x, int64_t rows, int64_t cols, int64_t ldx, int mode, int period,
+                 void* workspace, float* mean, float* var_biased, float* running_mean,
+                 float* running_var, float momentum, mla_stream_t stream);
+
+/* y = act((x - mean[c]) / sqrt(var[c] + eps) * gamma[c] + beta[c]), then optional dropout:
+ * y = keep_mask ? y * drop_scale : 0 (keep_mask: rows*cols bytes or NULL). act: 0 none, 1 ReLU
+ * (model.py:219), 2 sigmoid (model.py:268). Channel modes as mla_bn_stats. In eval mode the
+ * caller passes the running statistics, in train mode the batch statistics. */
+int mla_bn_apply(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t cols, int mode,
+                 int period, const float* mean, const float* var, const float* gamma, const float* beta,
+                 float eps, int act, const uint8_t* keep_mask, float drop_scale, mla_stream_t stream);
+
+/* model.AttentionModule.forward (model.py:236-242) after the fcv Linear: z (bags*T, K) ->
+ * y (bags, K) written with leading dimension ldy (so levels concatenate in place,
+ * model.py:267). BatchNorm parameters of normv (v_*) and normf (f_*) per time slot (T values).
+ * att_out / cla_out (bags*T*K each) receive softmax / sigmoid for the backward pass, or NULL. */
+int mla_attention_pool(const float* z, int64_t bags, int T, int K, const float* v_mean, const float* v_var,
+                       const float* v_gamma, const float* v_beta, const float* f_mean, const float* f_var,
+                       const float* f_gamma, const float* f_beta, float eps, float* y, int64_t ldy,
+                       float* att_out, float* cla_out, mla_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
