@@ -78,9 +78,10 @@ def waveforms_to_examples(pcm, out_dtype=torch.float32, out=None):
     pcm_code = {torch.float32: _lib.F32, torch.int16: _lib.I16}[pcm.dtype]
     out_code = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}[out_dtype]
     tab = device_tables(pcm.device)
-    _lib.check(_lib.lib().mla_logmel_examples(
-        ctypes.c_void_p(pcm.data_ptr()), pcm_code, n_wave, n_samples, pcm.stride(0),
-        ctypes.c_void_p(tab.data_ptr()), ctypes.c_void_p(out.data_ptr()), out_code, _lib.stream_ptr()))
+    from . import ops
+    _lib.check(ops._timed("logmel", _lib.lib().mla_logmel_examples,
+                          ctypes.c_void_p(pcm.data_ptr()), pcm_code, n_wave, n_samples, pcm.stride(0),
+                          ctypes.c_void_p(tab.data_ptr()), ctypes.c_void_p(out.data_ptr()), out_code, _lib.stream_ptr()))
     return out
 
 

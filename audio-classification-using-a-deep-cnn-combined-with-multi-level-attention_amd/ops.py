@@ -11,6 +11,21 @@ from . import _lib
 DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.int16: _lib.I16}
 BN_EPS = 1e-5
 
+# Optional per-kernel timing (bench.py): when `profile` is a list, every wrapped call appends
+# (name, start_event, end_event) recorded on the current stream -- the stream the kernels run on.
+profile = None
+
+
+def _timed(name, fn, *args):
+    if profile is None:
+        return fn(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn(*args)
+    e1.record()
+    profile.append((name, e0, e1))
+    return rc
+
 
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
@@ -52,7 +67,7 @@ def conv1(x, w, b, dtype):
     n = x.shape[0]
     assert tuple(x.shape[1:]) == (96, 64) and tuple(w.shape) == (64, 1, 3, 3)
     out = torch.empty((n, 48, 32, 64), dtype=dtype, device=x.device)
-    _lib.check(_lib.lib().mla_vggish_conv1(_p(x), DT[x.dtype], n, _p(w), _p(b), _p(out), DT[dtype], _lib.stream_ptr()))
+    _lib.check(_timed("conv1", _lib.lib().mla_vggish_conv1, _p(x), DT[x.dtype], n, _p(w), _p(b), _p(out), DT[dtype], _lib.stream_ptr()))
     return out
 
 
@@ -68,7 +83,7 @@ def conv(layer, x, w_packed, b):
     assert tuple(w_packed.shape) == (shp_out[2], 9, shp_in[2])
     n = x.shape[0]
     out = torch.empty((n,) + shp_out, dtype=x.dtype, device=x.device)
-    _lib.check(_lib.lib().mla_vggish_conv(layer, _p(x), _p(w_packed), _p(b), _p(out), n, DT[x.dtype], _lib.stream_ptr()))
+    _lib.check(_timed("conv%d" % layer, _lib.lib().mla_vggish_conv, layer, _p(x), _p(w_packed), _p(b), _p(out), n, DT[x.dtype], _lib.stream_ptr()))
     return out
 
 
@@ -80,8 +95,8 @@ def linear(a, w, b, relu=False, out_dtype=None):
     assert w.shape[1] == K
     out_dtype = out_dtype or a.dtype
     out = torch.empty((M, N), dtype=out_dtype, device=a.device)
-    _lib.check(_lib.lib().mla_linear(_p(a), a.stride(0), _p(w), w.stride(0), _p(b), _p(out), N, M, N, K, DT[a.dtype],
-                                     DT[out_dtype], int(relu), _lib.stream_ptr()))
+    _lib.check(_timed("linear_%dx%d" % (K, N), _lib.lib().mla_linear, _p(a), a.stride(0), _p(w), w.stride(0), _p(b), _p(out), N,
+                      M, N, K, DT[a.dtype], DT[out_dtype], int(relu), _lib.stream_ptr()))
     return out
 
 
