@@ -58,6 +58,19 @@ def lib():
         L.mla_bn_stats.argtypes = [vp, i64, i64, i64, ci, ci, vp, vp, vp, vp, vp, cf, vp]
         L.mla_bn_apply.argtypes = [vp, i64, vp, i64, i64, i64, ci, ci, vp, vp, vp, vp, cf, ci, vp, cf, vp]
         L.mla_attention_pool.argtypes = [vp, i64, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, vp, i64, vp, vp, vp]
+        cd = ctypes.c_double
+        L.mla_bn_stats_sums.argtypes = [vp, i64, i64, i64, ci, ci, vp, vp, vp]
+        L.mla_bn_stats_finish.argtypes = [vp, ci, cd, vp, vp, vp, vp, cf, vp]
+        L.mla_bn_bwd_sums.argtypes = [vp, i64, vp, i64, vp, i64, ci, cf, i64, i64, ci, ci, vp, vp, cf, vp, vp, vp]
+        L.mla_bn_bwd_apply.argtypes = [vp, i64, vp, i64, vp, i64, ci, cf, i64, i64, ci, ci, vp, vp, vp, cf, vp, vp, cd,
+                                       vp, i64, ci, vp, vp, vp]
+        L.mla_attention_pool_bwd.argtypes = [vp, i64, vp, vp, i64, ci, ci, vp, vp, vp]
+        L.mla_linear_small_bwd.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, vp, i64, vp, vp, vp]
+        L.mla_transpose_f32.argtypes = [vp, i64, vp, i64, i64, i64, vp]
+        L.mla_col_sum.argtypes = [vp, i64, i64, i64, vp, vp, vp]
+        L.mla_axpy.argtypes = [cf, vp, vp, i64, vp]
+        L.mla_cross_entropy.argtypes = [vp, i64, vp, i64, ci, cf, vp, vp, i64, vp, vp]
+        L.mla_adam_step.argtypes = [vp, vp, vp, vp, i64, cf, cf, cf, cf, i64, vp]
         _lib = L
     return _lib
 

@@ -1,17 +1,20 @@
 // mla_head.hip -- the small, HBM/launch-bound pieces of the multi-level-attention head
-// (reference: model.py:200-269). The Linear layers go through gemm.hip; here:
+// (reference: model.py:200-269), forward and backward. The Linear layers go through gemm.hip.
 //
 //   bn_stats / bn_apply   torch.nn.BatchNorm1d as the reference uses it (model.py:205, :213,
-//                         :232-233, :256). On a (B, T, F) tensor BatchNorm1d(T) takes the TIME
+//   bn_bwd_*              :232-233, :256). On a (B, T, F) tensor BatchNorm1d(T) takes the TIME
 //                         SLOT as channel: statistics over (batch, feature) per t ("row-periodic"
 //                         mode on the flattened (B*T, F) matrix, channel = row % T); on the (B, K)
 //                         logits BatchNorm1d(K) is per column. Train mode: biased batch variance
 //                         for normalisation, unbiased for the running update (momentum 0.1).
-//                         bn_apply fuses the affine, ReLU / sigmoid and the dropout mask.
-//   attention_pool        model.py:237-240: att = softmax_K(BNv(z)), cla = sigmoid(BNf(z)) on the
+//                         bn_apply fuses the affine, ReLU / sigmoid and the dropout mask; the
+//                         backward takes the gradient back through the same fused tail.
+//                         Statistics are split in two stages (local sums -> finish) so that
+//                         data-parallel ranks can all-reduce the sums in between (SyncBN).
+//   attention_pool(_bwd)  model.py:237-240: att = softmax_K(BNv(z)), cla = sigmoid(BNf(z)) on the
 //                         SAME z = fcv(h) (the reference never uses fcf), att normalised over T,
 //                         y = sum_T cla * att. 16 lanes per bag, shuffle reductions.
-//   linear_small          model.py:255/:268 fc (L*K -> K): too small / unaligned for the MFMA GEMM.
+//   linear_small(_bwd)    model.py:255/:268 fc (L*K -> K): too small / unaligned for the MFMA GEMM.
 //
 // Reductions are deterministic: per-block double-precision partials in a caller-provided
 // workspace, combined in fixed order by a single finishing block.
@@ -27,9 +30,39 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+__device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + __expf(-v)); }
+
+// gradient entering the BatchNorm output, taken back through the fused activation / dropout
+__device__ __forceinline__ float grad_through_act(float dy, float yout, int act, float drop_scale) {
+    if (act == 1) return yout > 0.f ? dy * drop_scale : 0.f;    // ReLU (+ dropout): yout = keep ? relu * scale : 0
+    if (act == 2) return dy * yout * (1.f - yout);              // sigmoid
+    return dy;
+}
+
+// element functors of the per-channel reductions: (row, col, channel) -> the two summands
+struct StatsOp {                        // forward statistics: (x, x^2)
+    const float* x; int64_t ldx;
+    __device__ __forceinline__ void operator()(int64_t r, int c, int, double& a, double& b) const {
+        const double v = x[r * ldx + c];
+        a = v; b = v * v;
+    }
+};
+
+struct BwdOp {                          // backward: (g, g * xhat)
+    const float *x, *dy, *yout, *mean, *var;
+    int64_t ldx, ld_dy, ld_y;
+    int act;
+    float drop_scale, eps;
+    __device__ __forceinline__ void operator()(int64_t r, int c, int ch, double& a, double& b) const {
+        const float g = grad_through_act(dy[r * ld_dy + c], yout ? yout[r * ld_y + c] : 0.f, act, drop_scale);
+        const float xhat = (x[r * ldx + c] - mean[ch]) * (1.0f / sqrtf(var[ch] + eps));
+        a = g; b = double(g) * xhat;
+    }
+};
+
 // mode 0: channel = row % period; one wave per row, lanes stride the columns
-__global__ __launch_bounds__(256) void stats_rows_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ldx,
-                                                         int period, double* __restrict__ partial) {
+template <typename Op>
+__global__ __launch_bounds__(256) void sums_rows_kernel(Op op, int64_t rows, int cols, int period, double* __restrict__ partial) {
     __shared__ double part[4][kMaxChannels][2];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < 4 * kMaxChannels * 2; i += 256) (&part[0][0][0])[i] = 0.0;
@@ -38,19 +71,19 @@ __global__ __launch_bounds__(256) void stats_rows_kernel(const float* __restrict
     const int64_t r0 = int64_t(blockIdx.x) * per_block;
     const int64_t r1 = r0 + per_block < rows ? r0 + per_block : rows;
     for (int64_t r = r0 + wave; r < r1; r += 4) {
-        const float* row = x + r * ldx;
+        const int chan = int(r % period);
         double s = 0.0, ss = 0.0;
         for (int c = lane; c < cols; c += 64) {
-            const double v = row[c];
-            s += v;
-            ss += v * v;
+            double a, b;
+            op(r, c, chan, a, b);
+            s += a;
+            ss += b;
         }
         s = wave_sum(s);
         ss = wave_sum(ss);
         if (lane == 0) {
-            const int ch = int(r % period);
-            part[wave][ch][0] += s;
-            part[wave][ch][1] += ss;
+            part[wave][chan][0] += s;
+            part[wave][chan][1] += ss;
         }
     }
     __syncthreads();
@@ -63,8 +96,8 @@ __global__ __launch_bounds__(256) void stats_rows_kernel(const float* __restrict
 }
 
 // mode 1: channel = column (cols <= 64); thread (g, c) walks rows g, g + G, ...
-__global__ __launch_bounds__(256) void stats_cols_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ldx,
-                                                         double* __restrict__ partial) {
+template <typename Op>
+__global__ __launch_bounds__(256) void sums_cols_kernel(Op op, int64_t rows, int cols, double* __restrict__ partial) {
     __shared__ double part[256][2];
     const int groups = 256 / cols, g = threadIdx.x / cols, c = threadIdx.x % cols;
     double s = 0.0, ss = 0.0;
@@ -73,9 +106,10 @@ __global__ __launch_bounds__(256) void stats_cols_kernel(const float* __restrict
         const int64_t r0 = int64_t(blockIdx.x) * per_block;
         const int64_t r1 = r0 + per_block < rows ? r0 + per_block : rows;
         for (int64_t r = r0 + g; r < r1; r += groups) {
-            const double v = x[r * ldx + c];
-            s += v;
-            ss += v * v;
+            double a, b;
+            op(r, c, c, a, b);
+            s += a;
+            ss += b;
         }
     }
     part[threadIdx.x][0] = s;
@@ -89,15 +123,42 @@ __global__ __launch_bounds__(256) void stats_cols_kernel(const float* __restrict
     }
 }
 
-__global__ void stats_finish_kernel(const double* __restrict__ partial, int blocks, int channels, double count,
-                                    float* __restrict__ mean, float* __restrict__ var, float* __restrict__ run_mean,
-                                    float* __restrict__ run_var, float momentum) {
+// fixed-order combination of the per-block partials -> sums[channel][2]
+__global__ void partial_reduce_kernel(const double* __restrict__ partial, int blocks, int channels, double* __restrict__ sums) {
     const int c = threadIdx.x;
     if (c >= channels) return;
     double s = 0.0, ss = 0.0;
     for (int b = 0; b < blocks; ++b) { s += partial[(int64_t(b) * channels + c) * 2]; ss += partial[(int64_t(b) * channels + c) * 2 + 1]; }
-    const double m = s / count;
-    double v = ss / count - m * m;
+    sums[2 * c] = s;
+    sums[2 * c + 1] = ss;
+}
+
+template <typename Op>
+int channel_sums(Op op, int64_t rows, int64_t cols, int mode, int period, void* workspace, double* sums, hipStream_t s) {
+    double* partial = static_cast<double*>(workspace);
+    const int channels = mode == 0 ? period : int(cols);
+    int blocks;
+    if (mode == 0) {
+        const int64_t groups = rows / period;
+        blocks = int(groups < kStatBlocks ? groups : kStatBlocks);
+        hipLaunchKernelGGL(sums_rows_kernel<Op>, dim3(blocks), dim3(256), 0, s, op, rows, int(cols), period, partial);
+    } else {
+        blocks = int((rows + 63) / 64 < kStatBlocks ? (rows + 63) / 64 : kStatBlocks);
+        hipLaunchKernelGGL(sums_cols_kernel<Op>, dim3(blocks), dim3(256), 0, s, op, rows, int(cols), partial);
+    }
+    MLA_LAUNCH_OK("channel sums");
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(1), dim3(64), 0, s, partial, blocks, channels, sums);
+    MLA_LAUNCH_OK("channel sums reduce");
+    return MLA_OK;
+}
+
+__global__ void stats_finish_kernel(const double* __restrict__ sums, int channels, double count, float* __restrict__ mean,
+                                    float* __restrict__ var, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                    float momentum) {
+    const int c = threadIdx.x;
+    if (c >= channels) return;
+    const double m = sums[2 * c] / count;
+    double v = sums[2 * c + 1] / count - m * m;
     if (v < 0.0) v = 0.0;
     mean[c] = float(m);
     var[c] = float(v);
@@ -107,8 +168,6 @@ __global__ void stats_finish_kernel(const double* __restrict__ partial, int bloc
         run_var[c] = float((1.0 - momentum) * run_var[c] + momentum * unbiased);
     }
 }
-
-__device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + __expf(-v)); }
 
 // y = act((x - mean[c]) * rsqrt(var[c] + eps) * gamma[c] + beta[c]) * keep * drop_scale
 template <int MODE>
@@ -129,6 +188,36 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         else if (act == 2) v = sigmoidf(v);
         if (keep) v = keep[i] ? v * drop_scale : 0.f;
         y[r * ldy + c] = v;
+    }
+}
+
+// dx = gamma * inv * (g - sum(g)/N - xhat * sum(g xhat)/N), written or accumulated.
+// sums_global drive dx (all-reduced over ranks under SyncBN); dgamma/dbeta come from sums_local.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BwdOp op, const float* __restrict__ gamma, int64_t rows, int cols,
+                                                           int period, const double* __restrict__ sums_global,
+                                                           const double* __restrict__ sums_local, double count,
+                                                           float* __restrict__ dx, int64_t ld_dx, int accumulate,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int channels = MODE == 0 ? period : cols;
+    if (blockIdx.x == 0 && threadIdx.x < channels && dgamma) {
+        dbeta[threadIdx.x] = float(sums_local[2 * threadIdx.x]);
+        dgamma[threadIdx.x] = float(sums_local[2 * threadIdx.x + 1]);
+    }
+    if (!dx) return;
+    const int64_t total = rows * cols;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < total; i += int64_t(gridDim.x) * 256) {
+        const int64_t r = i / cols;
+        const int c = int(i - r * cols);
+        const int ch = MODE == 0 ? int(r % period) : c;
+        double g, gx;
+        op(r, c, ch, g, gx);
+        const float inv = 1.0f / sqrtf(op.var[ch] + op.eps);
+        const float xhat = (op.x[r * op.ldx + c] - op.mean[ch]) * inv;
+        const float sg = float(sums_global[2 * ch] / count), sgx = float(sums_global[2 * ch + 1] / count);
+        const float v = gamma[ch] * inv * (float(g) - sg - xhat * sgx);
+        float* o = dx + r * ld_dx + c;
+        *o = accumulate ? *o + v : v;
     }
 }
 
@@ -179,6 +268,46 @@ __global__ __launch_bounds__(256) void attention_pool_kernel(const float* __rest
     }
 }
 
+// backward of the pooling given dy (bags, K): gradients w.r.t. the two BatchNorm outputs
+//   y = sum_t cla n,  n = att / S,  S = sum_t att
+//   d cla = dy n ;  d att = dy (cla - y) / S
+//   du_f = d cla * cla (1 - cla) ;  du_v = att * (d att - sum_k d att * att)      (softmax over k)
+template <int KMAX>
+__global__ __launch_bounds__(256) void attention_pool_bwd_kernel(const float* __restrict__ dy, int64_t ld_dy,
+                                                                 const float* __restrict__ att_in, const float* __restrict__ cla_in,
+                                                                 int64_t bags, int T, int K, float* __restrict__ du_v,
+                                                                 float* __restrict__ du_f) {
+    const int t = threadIdx.x & 15;
+    const int64_t bag = int64_t(blockIdx.x) * 16 + (threadIdx.x >> 4);
+    const bool live = bag < bags && t < T;
+    float att[KMAX], cla[KMAX], datt[KMAX];
+    _Pragma("unroll") for (int k = 0; k < KMAX; ++k) {
+        att[k] = (live && k < K) ? att_in[(bag * T + t) * K + k] : 0.f;
+        cla[k] = (live && k < K) ? cla_in[(bag * T + t) * K + k] : 0.f;
+    }
+    float dot = 0.f;
+    _Pragma("unroll") for (int k = 0; k < KMAX; ++k) {
+        datt[k] = 0.f;
+        if (k < K) {
+            float s = att[k];
+            _Pragma("unroll") for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+            float yk = live ? cla[k] * (att[k] / s) : 0.f;
+            _Pragma("unroll") for (int o = 8; o > 0; o >>= 1) yk += __shfl_xor(yk, o, 16);
+            if (live) {
+                const float g = dy[bag * ld_dy + k];
+                const float dcla = g * (att[k] / s);
+                datt[k] = g * (cla[k] - yk) / s;
+                du_f[(bag * T + t) * K + k] = dcla * cla[k] * (1.f - cla[k]);
+                dot += datt[k] * att[k];
+            }
+        }
+    }
+    if (live) {
+        _Pragma("unroll") for (int k = 0; k < KMAX; ++k)
+            if (k < K) du_v[(bag * T + t) * K + k] = att[k] * (datt[k] - dot);
+    }
+}
+
 __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ a, int64_t lda,
                                                            const float* __restrict__ w, int64_t ldw,
                                                            const float* __restrict__ bias, float* __restrict__ out,
@@ -192,38 +321,66 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
     out[m * ldo + n] = acc;
 }
 
+// backward of out = a w^T + b for tiny N, K: da (M, K) = dz w ; dw (N, K) = dz^T a ; db (N) = sum_m dz
+__global__ __launch_bounds__(256) void linear_small_bwd_kernel(const float* __restrict__ a, int64_t lda,
+                                                               const float* __restrict__ w, int64_t ldw,
+                                                               const float* __restrict__ dz, int64_t ldz, int64_t M, int N, int K,
+                                                               float* __restrict__ da, int64_t ldda, float* __restrict__ dw,
+                                                               float* __restrict__ db) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < M * K) {
+        const int64_t m = i / K;
+        const int k = int(i - m * K);
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) acc = fmaf(dz[m * ldz + n], w[int64_t(n) * ldw + k], acc);
+        da[m * ldda + k] = acc;
+    }
+    if (i < int64_t(N) * K) {                          // one thread per weight, fixed summation order over m
+        const int n = int(i / K), k = int(i % K);
+        double acc = 0.0;
+        for (int64_t m = 0; m < M; ++m) acc += double(dz[m * ldz + n]) * a[m * lda + k];
+        dw[int64_t(n) * K + k] = float(acc);
+    }
+    if (i < N) {
+        double acc = 0.0;
+        for (int64_t m = 0; m < M; ++m) acc += dz[m * ldz + i];
+        db[i] = float(acc);
+    }
+}
+
 }  // namespace
 
-extern "C" int64_t mla_bn_stats_workspace_bytes(void) { return int64_t(kStatBlocks) * kMaxChannels * 2 * sizeof(double); }
+extern "C" int64_t mla_bn_stats_workspace_bytes(void) { return (int64_t(kStatBlocks) + 1) * kMaxChannels * 2 * sizeof(double); }
 
-extern "C" int mla_bn_stats(const float* x, int64_t rows, int64_t cols, int64_t ldx, int mode, int period, void* workspace,
-                            float* mean, float* var_biased, float* running_mean, float* running_var, float momentum,
-                            mla_stream_t stream) {
-    MLA_REQUIRE(x && workspace && mean && var_biased && rows > 0 && cols > 0 && ldx >= cols, MLA_E_ARG, "bad bn_stats arguments");
+extern "C" int mla_bn_stats_sums(const float* x, int64_t rows, int64_t cols, int64_t ldx, int mode, int period, void* workspace,
+                                 double* sums, mla_stream_t stream) {
+    MLA_REQUIRE(x && workspace && sums && rows > 0 && cols > 0 && ldx >= cols, MLA_E_ARG, "bad bn_stats arguments");
     MLA_REQUIRE(mode == 0 || mode == 1, MLA_E_ARG, "bn_stats mode %d", mode);
     const int channels = mode == 0 ? period : int(cols);
     MLA_REQUIRE(channels >= 1 && channels <= kMaxChannels, MLA_E_SHAPE, "bn_stats supports 1..%d channels (got %d)", kMaxChannels, channels);
     MLA_REQUIRE(mode == 1 || rows % period == 0, MLA_E_SHAPE, "rows %lld not a multiple of period %d", (long long)rows, period);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    double* partial = static_cast<double*>(workspace);
-    int blocks;
-    double count;
-    if (mode == 0) {
-        const int64_t groups = rows / period;
-        blocks = int(groups < kStatBlocks ? groups : kStatBlocks);
-        count = double(groups) * double(cols);
-        hipLaunchKernelGGL(stats_rows_kernel, dim3(blocks), dim3(256), 0, s, x, rows, int(cols), ldx, period, partial);
-        // blocks whose row range is empty still write zero partials (per_block rounding): all `blocks` slots are valid
-    } else {
-        blocks = int((rows + 63) / 64 < kStatBlocks ? (rows + 63) / 64 : kStatBlocks);
-        count = double(rows);
-        hipLaunchKernelGGL(stats_cols_kernel, dim3(blocks), dim3(256), 0, s, x, rows, int(cols), ldx, partial);
-    }
-    MLA_LAUNCH_OK("bn stats");
-    hipLaunchKernelGGL(stats_finish_kernel, dim3(1), dim3(64), 0, s, partial, blocks, channels, count, mean, var_biased,
-                       running_mean, running_var, momentum);
+    return channel_sums(StatsOp{x, ldx}, rows, cols, mode, period, workspace, sums, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mla_bn_stats_finish(const double* sums, int channels, double count, float* mean, float* var_biased,
+                                   float* running_mean, float* running_var, float momentum, mla_stream_t stream) {
+    MLA_REQUIRE(sums && mean && var_biased && channels >= 1 && channels <= kMaxChannels && count > 0, MLA_E_ARG, "bad bn_stats_finish arguments");
+    hipLaunchKernelGGL(stats_finish_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), sums, channels, count, mean,
+                       var_biased, running_mean, running_var, momentum);
     MLA_LAUNCH_OK("bn stats finish");
     return MLA_OK;
+}
+
+extern "C" int mla_bn_stats(const float* x, int64_t rows, int64_t cols, int64_t ldx, int mode, int period, void* workspace,
+                            float* mean, float* var_biased, float* running_mean, float* running_var, float momentum,
+                            mla_stream_t stream) {
+    MLA_REQUIRE(workspace, MLA_E_ARG, "null workspace");
+    double* sums = static_cast<double*>(workspace) + int64_t(kStatBlocks) * kMaxChannels * 2;   // tail of the workspace
+    const int rc = mla_bn_stats_sums(x, rows, cols, ldx, mode, period, workspace, sums, stream);
+    if (rc != MLA_OK) return rc;
+    const int channels = mode == 0 ? period : int(cols);
+    const double count = mode == 0 ? double(rows / period) * double(cols) : double(rows);
+    return mla_bn_stats_finish(sums, channels, count, mean, var_biased, running_mean, running_var, momentum, stream);
 }
 
 extern "C" int mla_bn_apply(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t cols, int mode,
@@ -246,6 +403,38 @@ extern "C" int mla_bn_apply(const float* x, int64_t ldx, float* y, int64_t ldy, 
     return MLA_OK;
 }
 
+extern "C" int mla_bn_bwd_sums(const float* x, int64_t ldx, const float* dy, int64_t ld_dy, const float* yout, int64_t ld_y,
+                               int act, float drop_scale, int64_t rows, int64_t cols, int mode, int period, const float* mean,
+                               const float* var, float eps, void* workspace, double* sums, mla_stream_t stream) {
+    MLA_REQUIRE(x && dy && mean && var && workspace && sums && rows > 0 && cols > 0, MLA_E_ARG, "bad bn_bwd_sums arguments");
+    MLA_REQUIRE(act == 0 || yout, MLA_E_ARG, "bn_bwd needs the forward output for act %d", act);
+    MLA_REQUIRE((mode == 0 && period >= 1 && period <= kMaxChannels && rows % period == 0) || (mode == 1 && cols <= kMaxChannels),
+                MLA_E_SHAPE, "bn_bwd channel layout");
+    BwdOp op{x, dy, yout, mean, var, ldx, ld_dy, ld_y, act, drop_scale, eps};
+    return channel_sums(op, rows, cols, mode, period, workspace, sums, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mla_bn_bwd_apply(const float* x, int64_t ldx, const float* dy, int64_t ld_dy, const float* yout, int64_t ld_y,
+                                int act, float drop_scale, int64_t rows, int64_t cols, int mode, int period, const float* mean,
+                                const float* var, const float* gamma, float eps, const double* sums_global,
+                                const double* sums_local, double count, float* dx, int64_t ld_dx, int accumulate,
+                                float* dgamma, float* dbeta, mla_stream_t stream) {
+    MLA_REQUIRE(x && dy && mean && var && gamma && sums_global && sums_local && count > 0, MLA_E_ARG, "bad bn_bwd_apply arguments");
+    MLA_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), MLA_E_ARG, "dgamma and dbeta go together");
+    BwdOp op{x, dy, yout, mean, var, ldx, ld_dy, ld_y, act, drop_scale, eps};
+    const int64_t total = rows * cols;
+    const unsigned grid = dx ? unsigned((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192) : 1u;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (mode == 0)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3(grid), dim3(256), 0, s, op, gamma, rows, int(cols), period, sums_global,
+                           sums_local, count, dx, ld_dx, accumulate, dgamma, dbeta);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(grid), dim3(256), 0, s, op, gamma, rows, int(cols), period, sums_global,
+                           sums_local, count, dx, ld_dx, accumulate, dgamma, dbeta);
+    MLA_LAUNCH_OK("bn_bwd_apply");
+    return MLA_OK;
+}
+
 extern "C" int mla_attention_pool(const float* z, int64_t bags, int T, int K, const float* v_mean, const float* v_var,
                                   const float* v_gamma, const float* v_beta, const float* f_mean, const float* f_var,
                                   const float* f_gamma, const float* f_beta, float eps, float* y, int64_t ldy,
@@ -260,6 +449,17 @@ extern "C" int mla_attention_pool(const float* z, int64_t bags, int T, int K, co
     return MLA_OK;
 }
 
+extern "C" int mla_attention_pool_bwd(const float* dy, int64_t ld_dy, const float* att, const float* cla, int64_t bags, int T,
+                                      int K, float* du_v, float* du_f, mla_stream_t stream) {
+    MLA_REQUIRE(dy && att && cla && du_v && du_f && ld_dy >= K, MLA_E_ARG, "bad attention_pool_bwd arguments");
+    MLA_REQUIRE(T >= 1 && T <= 16 && K >= 1 && K <= 16, MLA_E_SHAPE, "attention_pool_bwd supports T, K <= 16 (got %d, %d)", T, K);
+    if (bags == 0) return MLA_OK;
+    hipLaunchKernelGGL(attention_pool_bwd_kernel<16>, dim3(unsigned((bags + 15) / 16)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), dy, ld_dy, att, cla, bags, T, K, du_v, du_f);
+    MLA_LAUNCH_OK("attention_pool_bwd");
+    return MLA_OK;
+}
+
 extern "C" int mla_linear_small(const float* a, int64_t lda, const float* w, int64_t ldw, const float* bias, float* out,
                                 int64_t ldo, int64_t M, int64_t N, int64_t K, mla_stream_t stream) {
     MLA_REQUIRE(a && w && out && M >= 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldo >= N, MLA_E_ARG, "bad linear_small arguments");
@@ -267,5 +467,16 @@ extern "C" int mla_linear_small(const float* a, int64_t lda, const float* w, int
     hipLaunchKernelGGL(linear_small_kernel, dim3(unsigned((M * N + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), a, lda, w, ldw, bias, out, ldo, M, int(N), int(K));
     MLA_LAUNCH_OK("linear_small");
+    return MLA_OK;
+}
+
+extern "C" int mla_linear_small_bwd(const float* a, int64_t lda, const float* w, int64_t ldw, const float* dz, int64_t ldz,
+                                    int64_t M, int64_t N, int64_t K, float* da, int64_t ldda, float* dw, float* db,
+                                    mla_stream_t stream) {
+    MLA_REQUIRE(a && w && dz && da && dw && db && M > 0 && N > 0 && K > 0, MLA_E_ARG, "bad linear_small_bwd arguments");
+    const int64_t work = M * K > N * K ? M * K : N * K;
+    hipLaunchKernelGGL(linear_small_bwd_kernel, dim3(unsigned((work + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a, lda, w, ldw, dz, ldz, M, int(N), int(K), da, ldda, dw, db);
+    MLA_LAUNCH_OK("linear_small_bwd");
     return MLA_OK;
 }

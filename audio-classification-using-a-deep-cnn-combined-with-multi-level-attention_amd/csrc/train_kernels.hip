@@ -1,0 +1,162 @@
+// train_kernels.hip -- the remaining pieces of the reference's inner training step
+// (train.py:124-138): cross-entropy on the sigmoid scores (train.py:372 nn.CrossEntropyLoss,
+// mean reduction, applied on top of model.py:268's sigmoid outputs), helpers for the Linear
+// backward (transposes feeding the MFMA GEMM, column sums for bias gradients), and the Adam
+// update (train.py:369 optim.Adam: betas 0.9/0.999, eps 1e-8, no weight decay, no amsgrad) over
+// one flat parameter buffer.
+#include "common.h"
+
+namespace {
+
+// out[c][r] = in[r][c]; 32x32 tiles through LDS (padded against bank conflicts)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int64_t ld_in, float* __restrict__ out,
+                                                        int64_t ld_out, int64_t rows, int64_t cols) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const int64_t c0 = int64_t(blockIdx.x) * 32, r0 = int64_t(blockIdx.y) * 32;
+    _Pragma("unroll") for (int j = 0; j < 32; j += 8) {
+        const int64_t r = r0 + ty + j, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + j][tx] = in[r * ld_in + c];
+    }
+    __syncthreads();
+    _Pragma("unroll") for (int j = 0; j < 32; j += 8) {
+        const int64_t c = c0 + ty + j, r = r0 + tx;
+        if (r < rows && c < cols) out[c * ld_out + r] = tile[tx][ty + j];
+    }
+}
+
+// loss = inv_total * sum_b (logsumexp(x_b) - x_b[y_b]);  dx = inv_total * (softmax(x_b) - onehot(y_b))
+// one block: deterministic double-precision reduction. inv_total = 1 / (global batch).
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ x, int64_t ldx,
+                                                            const int64_t* __restrict__ labels, int64_t rows, int K,
+                                                            float inv_total, float* __restrict__ loss, float* __restrict__ dx,
+                                                            int64_t ld_dx, int* __restrict__ n_correct) {
+    __shared__ double part[256];
+    __shared__ int hits[256];
+    double acc = 0.0;
+    int correct = 0;
+    for (int64_t b = threadIdx.x; b < rows; b += 256) {
+        const float* row = x + b * ldx;
+        float mx = row[0];
+        int arg = 0;
+        for (int k = 1; k < K; ++k)
+            if (row[k] > mx) { mx = row[k]; arg = k; }
+        float den = 0.f;
+        for (int k = 0; k < K; ++k) den += __expf(row[k] - mx);
+        const float lse = mx + __logf(den);
+        const int y = int(labels[b]);
+        acc += double(lse - row[y]);
+        correct += (arg == y);
+        if (dx)
+            for (int k = 0; k < K; ++k) dx[b * ld_dx + k] = (__expf(row[k] - lse) - (k == y ? 1.f : 0.f)) * inv_total;
+    }
+    part[threadIdx.x] = acc;
+    hits[threadIdx.x] = correct;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { part[threadIdx.x] += part[threadIdx.x + o]; hits[threadIdx.x] += hits[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *loss = float(part[0] * inv_total);
+        if (n_correct) *n_correct = hits[0];
+    }
+}
+
+// column sums of a (rows, cols) matrix: block (x = 64-column tile, y = row chunk) -> partials
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols,
+                                                             double* __restrict__ partial) {
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = int64_t(blockIdx.y) * per, r1 = r0 + per < rows ? r0 + per : rows;
+    double s = 0.0;
+    if (c < cols)
+        for (int64_t r = r0 + g; r < r1; r += 4) s += x[r * ldx + c];
+    part[g][lane] = s;
+    __syncthreads();
+    if (g == 0 && c < cols) partial[int64_t(blockIdx.y) * cols + c] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+}
+
+__global__ void colsum_finish_kernel(const double* __restrict__ partial, int chunks, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    double s = 0.0;
+    for (int k = 0; k < chunks; ++k) s += partial[int64_t(k) * cols + c];
+    out[c] = float(s);
+}
+
+__global__ void axpy_kernel(float a, const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) y[i] += a * x[i];
+}
+
+// torch.optim.Adam single-tensor step (no weight decay, no amsgrad):
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            int64_t n, float b1, float b2, float eps, float step_size, float inv_sqrt_bc2) {
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+
+unsigned grid_for(int64_t n) { return unsigned((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
+
+}  // namespace
+
+extern "C" int mla_transpose_f32(const float* in, int64_t ld_in, float* out, int64_t ld_out, int64_t rows, int64_t cols,
+                                 mla_stream_t stream) {
+    MLA_REQUIRE(in && out && rows > 0 && cols > 0 && ld_in >= cols && ld_out >= rows, MLA_E_ARG, "bad transpose arguments");
+    hipLaunchKernelGGL(transpose_kernel, dim3(unsigned((cols + 31) / 32), unsigned((rows + 31) / 32)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), in, ld_in, out, ld_out, rows, cols);
+    MLA_LAUNCH_OK("transpose");
+    return MLA_OK;
+}
+
+extern "C" int mla_cross_entropy(const float* x, int64_t ldx, const int64_t* labels, int64_t rows, int K, float inv_total,
+                                 float* loss, float* dx, int64_t ld_dx, int* n_correct, mla_stream_t stream) {
+    MLA_REQUIRE(x && labels && loss && rows > 0 && K >= 1 && ldx >= K, MLA_E_ARG, "bad cross_entropy arguments");
+    hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, labels, rows, K,
+                       inv_total, loss, dx, ld_dx, n_correct);
+    MLA_LAUNCH_OK("cross_entropy");
+    return MLA_OK;
+}
+
+// workspace: 64 * cols doubles
+extern "C" int mla_col_sum(const float* x, int64_t ldx, int64_t rows, int64_t cols, void* workspace, float* out,
+                           mla_stream_t stream) {
+    MLA_REQUIRE(x && workspace && out && rows > 0 && cols > 0 && ldx >= cols, MLA_E_ARG, "bad col_sum arguments");
+    const int chunks = int(rows / 256 < 1 ? 1 : (rows / 256 > 64 ? 64 : rows / 256));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(unsigned((cols + 63) / 64), unsigned(chunks)), dim3(256), 0, s, x, ldx, rows,
+                       int(cols), static_cast<double*>(workspace));
+    MLA_LAUNCH_OK("colsum partial");
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(unsigned((cols + 255) / 256)), dim3(256), 0, s,
+                       static_cast<const double*>(workspace), chunks, int(cols), out);
+    MLA_LAUNCH_OK("colsum finish");
+    return MLA_OK;
+}
+
+extern "C" int mla_axpy(float a, const float* x, float* y, int64_t n, mla_stream_t stream) {
+    MLA_REQUIRE(x && y && n >= 0, MLA_E_ARG, "bad axpy arguments");
+    if (n == 0) return MLA_OK;
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), a, x, y, n);
+    MLA_LAUNCH_OK("axpy");
+    return MLA_OK;
+}
+
+extern "C" int mla_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                             float eps, int64_t step, mla_stream_t stream) {
+    MLA_REQUIRE(p && g && m && v && n >= 0 && step >= 1, MLA_E_ARG, "bad adam arguments");
+    if (n == 0) return MLA_OK;
+    const double bc1 = 1.0 - pow(double(beta1), double(step)), bc2 = 1.0 - pow(double(beta2), double(step));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n, beta1, beta2,
+                       eps, float(double(lr) / bc1), float(1.0 / sqrt(bc2)));
+    MLA_LAUNCH_OK("adam");
+    return MLA_OK;
+}

@@ -87,14 +87,17 @@ def conv(layer, x, w_packed, b):
     return out
 
 
-def linear(a, w, b, relu=False, out_dtype=None):
-    """a (M, K), w (N, K) same dtype (f32 | bf16), bias f32 -> (M, N)."""
+def linear(a, w, b, relu=False, out_dtype=None, out=None):
+    """a (M, K), w (N, K) same dtype (f32 | bf16), bias f32 -> (M, N) (optionally into `out`)."""
     _chk(a); _chk(w, a.dtype)
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K
     out_dtype = out_dtype or a.dtype
-    out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    else:
+        assert out.is_contiguous() and out.numel() == M * N and out.dtype == out_dtype
     _lib.check(_timed("linear_%dx%d" % (K, N), _lib.lib().mla_linear, _p(a), a.stride(0), _p(w), w.stride(0), _p(b), _p(out), N,
                       M, N, K, DT[a.dtype], DT[out_dtype], int(relu), _lib.stream_ptr()))
     return out
@@ -155,3 +158,137 @@ def attention_pool(z, bags, T, K, nv, nf, y, save=False):
     _lib.check(_lib.lib().mla_attention_pool(_p(z), bags, T, K, _p(nv[0]), _p(nv[1]), _p(nv[2]), _p(nv[3]), _p(nf[0]), _p(nf[1]),
                                              _p(nf[2]), _p(nf[3]), BN_EPS, _p(y), y.stride(0), _p(att), _p(cla), _lib.stream_ptr()))
     return att, cla
+
+
+# ----------------------------------------------------------------- training-step kernels ----
+
+class Dist:
+    """Data-parallel context for the statistics exchanges (SyncBN) of the training step.
+    world == 1: every all-reduce is a no-op."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def all_reduce_sum(self, t):
+        """In-place sum over the group: RCCL (backend "nccl") directly on the device buffer; the
+        gloo backend (CPU rehearsals / tests) goes through a host copy."""
+        if self.world > 1:
+            import torch.distributed as dist
+            if t.is_cuda and dist.get_backend(self.group) == "gloo":
+                host = t.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(host)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+LOCAL = None          # set lazily (torch.distributed may not be initialised at import time)
+
+
+def _local():
+    global LOCAL
+    if LOCAL is None:
+        LOCAL = Dist.__new__(Dist)
+        LOCAL.group, LOCAL.world = None, 1
+    return LOCAL
+
+
+def bn_stats_sync(x, mode, period, dist, running_mean=None, running_var=None, momentum=-1.0):
+    """bn_stats with the (sum, sum of squares) all-reduced over the data-parallel group."""
+    _chk(x, torch.float32)
+    rows, cols = x.shape
+    ch = period if mode == 0 else cols
+    sums = torch.empty(2 * ch, dtype=torch.float64, device=x.device)
+    L = _lib.lib()
+    _lib.check(L.mla_bn_stats_sums(_p(x), rows, cols, x.stride(0), mode, period, _p(_workspace(x.device)), _p(sums), _lib.stream_ptr()))
+    dist.all_reduce_sum(sums)
+    count = (rows // period * cols if mode == 0 else rows) * dist.world
+    mean = torch.empty(ch, dtype=torch.float32, device=x.device)
+    var = torch.empty(ch, dtype=torch.float32, device=x.device)
+    _lib.check(L.mla_bn_stats_finish(_p(sums), ch, float(count), _p(mean), _p(var), _p(running_mean), _p(running_var),
+                                     float(momentum), _lib.stream_ptr()))
+    return mean, var
+
+
+def bn_backward(x, dy, yout, act, drop_scale, mode, period, mean, var, gamma, dist, dgamma, dbeta, want_dx=True,
+                dx=None, accumulate=False):
+    """BatchNorm (train mode) backward through the fused activation/dropout. Writes dgamma/dbeta
+    (local parts) and returns dx (global-batch exact under data parallelism)."""
+    _chk(x, torch.float32)
+    rows, cols = x.shape
+    ch = period if mode == 0 else cols
+    L = _lib.lib()
+    local = torch.empty(2 * ch, dtype=torch.float64, device=x.device)
+    ld_y = yout.stride(0) if yout is not None else 0
+    _lib.check(L.mla_bn_bwd_sums(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(yout), ld_y, act, float(drop_scale), rows, cols, mode,
+                                 period, _p(mean), _p(var), BN_EPS, _p(_workspace(x.device)), _p(local), _lib.stream_ptr()))
+    glob = local
+    if dist.world > 1:
+        glob = dist.all_reduce_sum(local.clone())
+    count = (rows // period * cols if mode == 0 else rows) * dist.world
+    if want_dx and dx is None:
+        dx = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
+    _lib.check(L.mla_bn_bwd_apply(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(yout), ld_y, act, float(drop_scale), rows, cols, mode,
+                                  period, _p(mean), _p(var), _p(gamma), BN_EPS, _p(glob), _p(local), float(count),
+                                  _p(dx) if want_dx else None, dx.stride(0) if want_dx else 0, int(accumulate), _p(dgamma),
+                                  _p(dbeta), _lib.stream_ptr()))
+    return dx
+
+
+def attention_pool_bwd(dy, att, cla, bags, T, K):
+    du_v, du_f = torch.empty_like(att), torch.empty_like(att)
+    _lib.check(_lib.lib().mla_attention_pool_bwd(_p(dy), dy.stride(0), _p(att), _p(cla), bags, T, K, _p(du_v), _p(du_f), _lib.stream_ptr()))
+    return du_v, du_f
+
+
+def linear_small_bwd(a, w, dz, dw, db):
+    M, K = a.shape
+    N = w.shape[0]
+    da = torch.empty((M, K), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().mla_linear_small_bwd(_p(a), a.stride(0), _p(w), w.stride(0), _p(dz), dz.stride(0), M, N, K, _p(da), K,
+                                               _p(dw), _p(db), _lib.stream_ptr()))
+    return da
+
+
+def transpose_padded(x):
+    """(R, C) f32 -> (C, ceil4(R)) with zero padding, K-contiguous for the MFMA GEMM."""
+    _chk(x, torch.float32)
+    R, C = x.shape
+    ld = (R + 3) // 4 * 4
+    out = torch.zeros((C, ld), dtype=torch.float32, device=x.device) if ld != R else torch.empty((C, ld), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mla_transpose_f32(_p(x), x.stride(0), _p(out), ld, R, C, _lib.stream_ptr()))
+    return out
+
+
+def col_sum(x, out):
+    _chk(x, torch.float32)
+    rows, cols = x.shape
+    ws = _workspace(x.device)
+    assert 64 * cols <= ws.numel()
+    _lib.check(_lib.lib().mla_col_sum(_p(x), x.stride(0), rows, cols, _p(ws), _p(out), _lib.stream_ptr()))
+    return out
+
+
+def axpy(a, x, y):
+    _lib.check(_lib.lib().mla_axpy(float(a), _p(x), _p(y), x.numel(), _lib.stream_ptr()))
+    return y
+
+
+def cross_entropy(scores, labels, inv_total, want_grad=True):
+    """CrossEntropyLoss(mean over the GLOBAL batch) on (B, K) scores: (loss, dscores, n_correct)."""
+    _chk(scores, torch.float32); _chk(labels, torch.int64)
+    B, K = scores.shape
+    loss = torch.empty(1, dtype=torch.float32, device=scores.device)
+    hits = torch.empty(1, dtype=torch.int32, device=scores.device)
+    d = torch.empty_like(scores) if want_grad else None
+    _lib.check(_lib.lib().mla_cross_entropy(_p(scores), scores.stride(0), _p(labels), B, K, float(inv_total), _p(loss), _p(d),
+                                            K, _p(hits), _lib.stream_ptr()))
+    return loss, d, hits
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
+    _lib.check(_lib.lib().mla_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                                        int(step), _lib.stream_ptr()))

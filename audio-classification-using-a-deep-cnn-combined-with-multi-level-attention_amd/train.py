@@ -1,0 +1,156 @@
+"""Drop-in for the hot-path part of the reference's ``train.py``: the inner training step
+(train.py:119-142), ``trainable_params`` (train.py:283-303), the Adam / CrossEntropyLoss choice
+(train.py:369-372) and ``H5Loader`` (train.py:31-48), plus a compact ``train_model`` epoch loop
+with the reference's signature. Plotting, sklearn reports and whole-object pickled checkpoints
+(train.py:182-281) are host orchestration outside SURVEY.md section 8 and are not reproduced.
+
+``TrainStep`` fuses zero_grad -> forward -> CrossEntropyLoss -> backward -> Adam into HIP kernel
+calls; under ``torch.distributed`` it shards nothing itself (each rank feeds its own bags) and
+exchanges (a) BatchNorm statistics (SyncBN, so the result equals the reference's single-process
+step on the global batch) and (b) ONE flat gradient buffer with an RCCL all-reduce over xGMI.
+"""
+
+import time
+
+import torch
+import torch.nn as nn
+from torch.utils.data import Dataset
+
+from . import mla_train, ops
+from .params import *  # noqa: F401,F403
+
+
+class H5Loader(Dataset):
+    """Dataset over array-likes (HDF5 datasets or ndarrays): train.py:31-48."""
+
+    def __init__(self, X_desc, y_desc):
+        self.X_desc, self.y_desc = X_desc, y_desc
+
+    def __len__(self):
+        return self.y_desc.shape[0]
+
+    def __getitem__(self, idx):
+        return (self.X_desc[idx], self.y_desc[idx])
+
+
+def trainable_params(model, feature_extract):
+    """train.py:283-303: the parameters to hand to the optimizer (prints their names)."""
+    params_to_update = model.parameters()
+    print("Params to learn:")
+    if feature_extract:
+        params_to_update = []
+        for name, param in model.named_parameters():
+            if param.requires_grad:
+                params_to_update.append(param)
+                print("\t", name)
+    else:
+        for name, param in model.named_parameters():
+            if param.requires_grad:
+                print("\t", name)
+    return params_to_update
+
+
+class TrainStep:
+    """One fused training step of an ``Ensemble`` (frozen CNN, the reference default
+    ``cnn_trainable=False``; model.py:159-160).
+
+    All trainable parameters are re-seated as views of ONE flat float32 buffer (same for
+    gradients and the two Adam moments), so the data-parallel exchange is a single all-reduce
+    and Adam a single kernel. ``attention_modules.*.fcf.*`` never receive a gradient
+    (model.py:237-238); like torch's Adam (which skips ``grad is None``) they are left untouched.
+    """
+
+    def __init__(self, clf, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+        self.clf, self.lr, self.betas, self.eps, self.t = clf, lr, betas, eps, 0
+        self.dist = ops.Dist(process_group)
+        cnn_trainable = [n for n, p in clf.cnn.named_parameters() if p.requires_grad]
+        if cnn_trainable:
+            raise NotImplementedError("finetune (CNN gradients: conv/FC dgrad + wgrad) is not built yet; "
+                                      "trainable CNN parameters: %s ..." % cnn_trainable[:3])
+        named = [(n, p) for n, p in clf.mla.named_parameters() if p.requires_grad and ".fcf." not in n]
+        dev = named[0][1].device
+        total = sum(p.numel() for _, p in named)
+        self.flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grads, off = {}, 0
+        for n, p in named:
+            k = p.numel()
+            self.flat_p[off:off + k].copy_(p.detach().reshape(-1))
+            p.data = self.flat_p[off:off + k].view(p.shape)
+            self.grads[n] = self.flat_g[off:off + k].view(p.shape)
+            off += k
+
+    def __call__(self, inputs, labels):
+        """inputs (B, T, 1, 96, 64) (or whatever ``clf.input`` reshapes), labels (B,) int64.
+        Returns (loss, n_correct) as device tensors (no host sync; train.py:141-142 syncs via .item())."""
+        clf = self.clf
+        clf.train()
+        B_global = inputs.shape[0] * self.dist.world
+        with torch.no_grad():
+            feats = clf.cnn(clf.input(inputs))
+            ctx = mla_train.Ctx(tape=True, dist=self.dist)
+            out = mla_train.mla_forward(clf.mla, feats.reshape(-1, T, clf.emb_input_size), ctx)
+            loss, dout, hits = ops.cross_entropy(out, labels.to(out.device).long().contiguous(), 1.0 / B_global)
+            mla_train.mla_backward(clf.mla, ctx, dout, self.grads)
+            if self.dist.world > 1:
+                self.dist.all_reduce_sum(self.flat_g)
+                self.dist.all_reduce_sum(loss)
+            self.t += 1
+            ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
+        self.last_out = out
+        return loss, hits
+
+
+def _evaluate(clf, loader, device):
+    clf.eval()
+    tot_loss, tot_hits, n = 0.0, 0, 0
+    with torch.no_grad():
+        for inputs, labels in loader:
+            inputs, labels = inputs.to(device).float(), labels.to(device).long()
+            out = clf(inputs)
+            loss, _, hits = ops.cross_entropy(out, labels.contiguous(), 1.0 / inputs.shape[0], want_grad=False)
+            tot_loss += float(loss) * inputs.shape[0]
+            tot_hits += int(hits)
+            n += inputs.shape[0]
+    return tot_loss / max(n, 1), tot_hits / max(n, 1)
+
+
+def train_model(clf, dataloaders, criterion, optimizer, num_epochs=25, patience=10, save_model_path=None, resume=False,
+                finetune=False):
+    """Epoch loop with the reference's signature and return value (train.py:53-179):
+    (model with the best-validation weights, validation accuracy history, test accuracy).
+    ``criterion`` must be nn.CrossEntropyLoss and ``optimizer`` torch.optim.Adam: their
+    hyper-parameters are read and the fused HIP step is used instead of autograd."""
+    if not isinstance(criterion, nn.CrossEntropyLoss) or not isinstance(optimizer, torch.optim.Adam):
+        raise TypeError("the HIP training step implements CrossEntropyLoss + Adam (train.py:369-372)")
+    if finetune or resume:
+        raise NotImplementedError("finetune / resume are outside the built hot path")
+    import copy
+    g = optimizer.param_groups[0]
+    device = next(clf.parameters()).device
+    step = TrainStep(clf, lr=g["lr"], betas=g["betas"], eps=g["eps"])
+    since, val_acc_history, best_acc, best_epoch = time.time(), [], 0.0, 0
+    best_wts = copy.deepcopy(clf.state_dict())
+    test_loader = dataloaders.pop("test", None)
+    for epoch in range(num_epochs):
+        print("Epoch {}/{}".format(epoch + 1, num_epochs)); print("-" * 10)
+        run_loss, run_hits, n = 0.0, 0, 0
+        for inputs, labels in dataloaders["train"]:
+            loss, hits = step(inputs.to(device).float(), labels.to(device))
+            run_loss += float(loss) * inputs.shape[0]; run_hits += int(hits); n += inputs.shape[0]
+        print("train Loss: {:.4f}, Acc: {:.4f}".format(run_loss / max(n, 1), run_hits / max(n, 1)))
+        v_loss, v_acc = _evaluate(clf, dataloaders["val"], device)
+        print("val Loss: {:.4f}, Acc: {:.4f}".format(v_loss, v_acc))
+        val_acc_history.append(v_acc)
+        if v_acc > best_acc:
+            best_acc, best_epoch, best_wts = v_acc, epoch, copy.deepcopy(clf.state_dict())
+            if save_model_path:
+                torch.save(clf.state_dict(), save_model_path)
+        if patience is not None and epoch - best_epoch >= patience:
+            break
+    print("Training complete in {:.0f}s; best val Acc: {:4f}".format(time.time() - since, best_acc))
+    clf.load_state_dict(best_wts)
+    test_acc = _evaluate(clf, test_loader, device)[1] if test_loader is not None else None
+    return clf, val_acc_history, test_acc

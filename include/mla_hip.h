@@ -153,6 +153,65 @@ int mla_attention_pool(const float* z, int64_t bags, int T, int K, const float* 
                        const float* f_gamma, const float* f_beta, float eps, float* y, int64_t ldy,
                        float* att_out, float* cla_out, mla_stream_t stream);
 
+/* Two-stage form of mla_bn_stats for data-parallel training: stage 1 writes the LOCAL
+ * per-channel (sum x, sum x^2) as 2*channels doubles; the host side may all-reduce them over
+ * ranks (SyncBN: the reference's single process sees the global batch); stage 2 turns sums +
+ * per-channel element count into mean / biased variance (+ running update). */
+int mla_bn_stats_sums(const float* x, int64_t rows, int64_t cols, int64_t ldx, int mode, int period,
+                      void* workspace, double* sums, mla_stream_t stream);
+int mla_bn_stats_finish(const double* sums, int channels, double count, float* mean, float* var_biased,
+                        float* running_mean, float* running_var, float momentum, mla_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Training step: train.py:124-138 (zero_grad, forward, CrossEntropyLoss, backward, Adam)
+ * ---------------------------------------------------------------------------------- */
+
+/* BatchNorm1d backward (train mode), through the activation/dropout fused in mla_bn_apply:
+ * g = dy taken through act (1: ReLU[+dropout] using the forward output yout, 2: sigmoid, 0: none).
+ * Stage 1: LOCAL per-channel (sum g, sum g*xhat) as 2*channels doubles (all-reducible).
+ * Stage 2: dx = gamma*inv*(g - sum g/N - xhat*sum(g xhat)/N) from the GLOBAL sums and count N
+ * (written, or added when accumulate != 0; NULL to skip) and dgamma/dbeta from the LOCAL sums
+ * (the gradient all-reduce adds the ranks' parts; NULL to skip). */
+int mla_bn_bwd_sums(const float* x, int64_t ldx, const float* dy, int64_t ld_dy, const float* yout, int64_t ld_y,
+                    int act, float drop_scale, int64_t rows, int64_t cols, int mode, int period, const float* mean,
+                    const float* var, float eps, void* workspace, double* sums, mla_stream_t stream);
+int mla_bn_bwd_apply(const float* x, int64_t ldx, const float* dy, int64_t ld_dy, const float* yout, int64_t ld_y,
+                     int act, float drop_scale, int64_t rows, int64_t cols, int mode, int period, const float* mean,
+                     const float* var, const float* gamma, float eps, const double* sums_global,
+                     const double* sums_local, double count, float* dx, int64_t ld_dx, int accumulate,
+                     float* dgamma, float* dbeta, mla_stream_t stream);
+
+/* Backward of mla_attention_pool: dy (bags, K; leading dim ld_dy) and the saved att / cla ->
+ * gradients w.r.t. the normv output (du_v) and the normf output (du_f), (bags*T, K) each. */
+int mla_attention_pool_bwd(const float* dy, int64_t ld_dy, const float* att, const float* cla, int64_t bags, int T,
+                           int K, float* du_v, float* du_f, mla_stream_t stream);
+
+/* Backward of mla_linear_small: da (M, K) = dz . w, dw (N, K) = dz^T . a, db (N) = column sums. */
+int mla_linear_small_bwd(const float* a, int64_t lda, const float* w, int64_t ldw, const float* dz, int64_t ldz,
+                         int64_t M, int64_t N, int64_t K, float* da, int64_t ldda, float* dw, float* db,
+                         mla_stream_t stream);
+
+/* out[c][r] = in[r][c] (f32). The Linear backward feeds the K-contiguous MFMA GEMM with
+ * transposed copies: dX = mla_linear(dZ, W^T), dW = mla_linear(dZ^T, X^T). */
+int mla_transpose_f32(const float* in, int64_t ld_in, float* out, int64_t ld_out, int64_t rows, int64_t cols,
+                      mla_stream_t stream);
+/* out[c] = sum_r x[r][c] (bias gradients). workspace: 64 * cols doubles. Deterministic. */
+int mla_col_sum(const float* x, int64_t ldx, int64_t rows, int64_t cols, void* workspace, float* out,
+                mla_stream_t stream);
+/* y += a * x */
+int mla_axpy(float a, const float* x, float* y, int64_t n, mla_stream_t stream);
+
+/* nn.CrossEntropyLoss (train.py:372) on scores x (rows, K) with int64 labels: writes
+ * loss = inv_total * sum_b (logsumexp(x_b) - x_b[y_b]) and, if dx != NULL,
+ * dx = inv_total * (softmax(x_b) - onehot(y_b)); n_correct (optional) = #argmax hits
+ * (train.py:133). inv_total = 1 / global batch (mean reduction across all ranks). */
+int mla_cross_entropy(const float* x, int64_t ldx, const int64_t* labels, int64_t rows, int K, float inv_total,
+                      float* loss, float* dx, int64_t ld_dx, int* n_correct, mla_stream_t stream);
+
+/* torch.optim.Adam step t (train.py:369; no weight decay, no amsgrad) over one flat buffer. */
+int mla_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int64_t step, mla_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

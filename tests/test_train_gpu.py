@@ -1,0 +1,90 @@
+"""GPU tests of the fused HIP training step (train.py:119-142 semantics) against the loss curve,
+gradients and updated parameters that the REFERENCE produced (tests/golden/train.npz), and of
+the data-parallel path (2 ranks == 1 rank on the global batch)."""
+
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PKG, ROOT
+
+pytestmark = pytest.mark.gpu
+
+NOISY = ("fc.bias", "fc.0.bias", "fc.1.bias", "fcv.bias")     # zero-gradient biases: see test_oracle_golden.py
+
+
+def build(mk, W):
+    M = importlib.import_module(PKG + ".model")
+    ens = M.Ensemble("repeat", dict(mk.CNN_CONF), [2, 1], torch.device("cuda"))
+    ens.load_state_dict({k: torch.as_tensor(v) for k, v in W.make_state_dict(7, W.ensemble_shapes((2, 1), False)).items()})
+    return ens.cuda()
+
+
+def install(ens, masks, lo=None, hi=None):
+    for lvl, em in enumerate(ens.mla.embedded_mappings):
+        for j, d in enumerate(em.dropouts):
+            d.mask = masks["mla.embedded_mappings.%d.dropouts.%d" % (lvl, j)][lo:hi]
+
+
+def test_training_curve_matches_reference_golden(golden, mk, W):
+    g = golden("train")
+    TR = importlib.import_module(PKG + ".train")
+    ens = build(mk, W)
+    step = TR.TrainStep(ens, lr=1e-3)
+    assert step.flat_p.numel() == 823050 - 2 * 6010, "trainable minus the dead fcf parameters"
+    losses = []
+    for s in range(10):
+        x, y = mk.synth_bags(100 + s, 8)
+        install(ens, mk.make_masks(200 + s, [2, 1], 8))
+        loss, hits = step(x.cuda(), y.cuda())
+        losses.append(float(loss))
+        if s == 0:
+            np.testing.assert_allclose(step.last_out.cpu().numpy(), g["frozen/out_first"], rtol=1e-4, atol=1e-5)
+            # (grads are read after Adam ran; Adam does not modify them)
+            for name, gr in step.grads.items():
+                ref = float(g["frozen/gradnorm0/mla." + name])
+                got = float(gr.double().norm())
+                if ref < 1e-4:
+                    assert got < 1e-4, name
+                else:
+                    assert got == pytest.approx(ref, rel=2e-3), name
+            np.testing.assert_allclose(step.grads["fc.weight"].cpu().numpy(), g["frozen/grad0/mla.fc.weight"], rtol=1e-3, atol=1e-6)
+            np.testing.assert_allclose(step.grads["embedded_mappings.0.norm0.weight"].cpu().numpy(),
+                                       g["frozen/grad0/mla.embedded_mappings.0.norm0.weight"], rtol=1e-3, atol=1e-6)
+            np.testing.assert_allclose(step.grads["attention_modules.1.fcv.weight"].cpu().numpy(),
+                                       g["frozen/grad0/mla.attention_modules.1.fcv.weight"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(losses, g["frozen/losses"], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(step.last_out.cpu().numpy(), g["frozen/out_last"], rtol=2e-3, atol=2e-4)
+    sd = ens.state_dict()
+    for k in g.files:
+        if k.startswith("frozen/final/") and not k.endswith(NOISY):
+            atol = 1e-2 if k.endswith("running_mean") else 2e-4
+            np.testing.assert_allclose(sd[k[len("frozen/final/"):]].cpu().numpy(), g[k], rtol=1e-3, atol=atol, err_msg=k)
+    fcf = sd["mla.attention_modules.0.fcf.bias"].cpu().numpy()
+    assert np.array_equal(fcf, W.make_tensor(7, "mla.attention_modules.0.fcf.bias", (10,))), "dead parameters stay untouched"
+    ens.eval()
+    ev = ens(mk.synth_bags(999, 4)[0].cuda())
+    np.testing.assert_allclose(ev.cpu().numpy(), g["frozen/eval_after"], rtol=0, atol=2e-2)
+
+
+def test_two_ranks_equal_one_rank_on_the_global_batch(tmp_path, golden):
+    """Data-parallel correctness by construction: SyncBN sums + 1/B_global loss scaling + one
+    gradient all-reduce reproduce the single-process step. Two ranks share the test GPU (gloo)."""
+    g = golden("train")
+    out = str(tmp_path / "dp")
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_worker.py"), out, "5", "8"],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    r0, r1 = np.load(out + ".rank0.npz"), np.load(out + ".rank1.npz")
+    np.testing.assert_allclose(r0["losses"], g["frozen/losses"][:5], rtol=2e-4, atol=1e-5)
+    np.testing.assert_array_equal(r0["losses"], r1["losses"])
+    for k in r0.files:
+        if k != "losses":
+            np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)      # replicas stay bit-identical
