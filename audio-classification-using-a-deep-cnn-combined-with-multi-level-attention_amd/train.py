@@ -69,8 +69,10 @@ class TrainStep:
                                       "trainable CNN parameters: %s ..." % cnn_trainable[:3])
         named = [(n, p) for n, p in clf.mla.named_parameters() if p.requires_grad and ".fcf." not in n]
         dev = named[0][1].device
-        total = sum(p.numel() for _, p in named)
-        self.flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+        pad4 = lambda k: (k + 3) // 4 * 4                 # every tensor starts 16-byte aligned (GEMM operand rule)
+        total = sum(pad4(p.numel()) for _, p in named)
+        self.n_params = sum(p.numel() for _, p in named)
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -80,7 +82,7 @@ class TrainStep:
             self.flat_p[off:off + k].copy_(p.detach().reshape(-1))
             p.data = self.flat_p[off:off + k].view(p.shape)
             self.grads[n] = self.flat_g[off:off + k].view(p.shape)
-            off += k
+            off += pad4(k)
 
     def __call__(self, inputs, labels):
         """inputs (B, T, 1, 96, 64) (or whatever ``clf.input`` reshapes), labels (B,) int64.
