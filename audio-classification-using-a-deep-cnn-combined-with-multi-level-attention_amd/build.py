@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libmla_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-value",
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-value", "-Wno-pass-failed",
          "-I", INCLUDE, "-I", CSRC]
 
 

@@ -47,6 +47,8 @@ struct Cfg {
     static constexpr int B_BYTES = BN * kRowBytes;
     static constexpr int LDS_BYTES = A_BYTES + 2 * B_BYTES;
     static constexpr int TILES_Y = H / TH;
+    static constexpr bool PERSIST = NS != 2;                // conv2 (half-width tile): two non-persistent workgroups per CU
+    static constexpr int MIN_WAVES = (PERSIST || sizeof(T) == 4) ? 2 : 4;      // waves per SIMD the register budget is held to
     static constexpr int HO = POOL ? H / 2 : H, WO = POOL ? W / 2 : W;
     static_assert(W == 32 || W == 16 || W == 8, "tile mapping covers the VGGish widths");
     static_assert(H % TH == 0 && CIN % KC == 0 && COUT % BN == 0, "shape must tile exactly");
@@ -56,14 +58,17 @@ struct Cfg {
 
 template <typename C>
 __device__ __forceinline__ int a_swizzle(int xh, int img) {
-    return C::SEGW == 16 ? ((xh >> 1) & 7) : (((xh >> 1) & 3) | ((img & 1) << 2));
+    // bits 1-2 only (see mma_core.h); for W = 8 the two images of a subtile occupy complementary
+    // x ranges inside each read class, so no image bit is needed.
+    (void)img;
+    return ((xh >> 1) & 3) << 1;
 }
 
 template <typename C>
-__global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const typename C::elem* __restrict__ in,
+__global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const typename C::elem* __restrict__ in,
                                                                const typename C::elem* __restrict__ wgt,
                                                                const float* __restrict__ bias,
-                                                               typename C::elem* __restrict__ out, int n_img) {
+                                                               typename C::elem* __restrict__ out, int n_img, int n_tiles) {
     using T = typename C::elem;
     constexpr int PER = Elem<T>::kPerChunk;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -72,10 +77,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const typename C::
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 2, wn = wave & 3;
     const int r = lane & 15, q = lane >> 4;
+    // Persistent workgroup: tiles blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is a multiple of
+    // TILES_Y, so the tile row `ty` -- and with it every per-lane global offset -- is fixed for life).
     const int ty = blockIdx.x % C::TILES_Y;
-    const int img0 = (blockIdx.x / C::TILES_Y) * C::IMGS;
     const int y_tile = ty * C::TH;
     const int n0 = blockIdx.y * C::BN;
+    int tile = blockIdx.x;
+    int img0 = (tile / C::TILES_Y) * C::IMGS;
 
     // this lane's pixel inside the tile (A-operand row r of every m-subtile of the wave)
     const int l_img = C::SEGW == 8 ? (r >> 3) : 0;
@@ -86,7 +94,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const typename C::
         const int xh = l_x + kx;
         abase[kx] = ((l_img * C::PH + l_y0) * C::PW + xh) * kRowBytes + 16 * (q ^ a_swizzle<C>(xh, l_img));
     }
-    const int bbase = (wn * C::NS * 16 + r) * kRowBytes + 16 * (q ^ ((r >> 1) & 7));
+    const int bbase = tile_off(wn * C::NS * 16 + r, q);
 
     f32x4 acc[kMS][C::NS];
     _Pragma("unroll") for (int i = 0; i < kMS; ++i)
@@ -94,98 +102,151 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_kernel(const typename C::
 
     constexpr int A_PIECES = C::IMGS * C::PH * C::PW * 8;
     constexpr int A_PASSES = (A_PIECES + kThreads - 1) / kThreads;
+    constexpr int CHUNKS = C::CIN / C::KC;
 
-    for (int c0 = 0; c0 < C::CIN; c0 += C::KC) {
-        __syncthreads();                      // every wave is done with sA / sB of the previous chunk
-        {   // input patch: global -> registers -> LDS (zero outside the image / past the batch)
-            u32x4 v[A_PASSES];
-            int dst[A_PASSES];
-            _Pragma("unroll") for (int p = 0; p < A_PASSES; ++p) {
-                const int piece = t + kThreads * p;
-                const int ch = piece & 7, pix = piece >> 3;
-                const int xh = pix % C::PW, rest = pix / C::PW;
-                const int yh = rest % C::PH, im = rest / C::PH;
-                const int gy = y_tile + yh - 1, gx = xh - 1, gi = img0 + im;
-                const bool ok = piece < A_PIECES && gy >= 0 && gy < C::H && gx >= 0 && gx < C::W && gi < n_img;
-                dst[p] = piece < A_PIECES
-                             ? ((im * C::PH + yh) * C::PW + xh) * kRowBytes + 16 * (ch ^ a_swizzle<C>(xh, im))
-                             : -1;
-                v[p] = zero16();
-                if (ok) {
-                    const size_t off = ((size_t(gi) * C::H + gy) * C::W + gx) * C::CIN + c0 + ch * PER;
-                    v[p] = *reinterpret_cast<const u32x4*>(in + off);
-                }
-            }
-            _Pragma("unroll") for (int p = 0; p < A_PASSES; ++p)
-                if (dst[p] >= 0) lds_write16(sA, dst[p], v[p]);
+    // Global operands through buffer descriptors (wave-uniform base, 32-bit per-lane offsets fixed
+    // for the whole kernel, scalar offset per tap / chunk). Out-of-image halo pixels and images past
+    // the batch get an out-of-range offset: the hardware range check returns zeros, no branches.
+    constexpr uint32_t ESZ = sizeof(T);
+    auto patch_rsrc = [&](int first_img) {     // descriptor over the tile's images (fewer at the batch tail)
+        const int imgs_here = (n_img - first_img) < C::IMGS ? (n_img - first_img) : C::IMGS;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in) + size_t(first_img) * C::H * C::W * C::CIN, 0,
+                                                 uint32_t(imgs_here) * C::H * C::W * C::CIN * ESZ, 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t a_rsrc = patch_rsrc(img0);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(wgt) + size_t(n0) * 9 * C::CIN, 0, uint32_t(C::BN) * 9 * C::CIN * ESZ, 0x00020000);
+    // Per-lane offsets are recomputed where they are used (once per chunk for the patch, ~2 VALU per
+    // weight piece) instead of being held in VGPRs across the MFMA loop: registers are the scarce
+    // resource here (96 accumulators + 40 fragment + 36 staging registers per lane).
+    u32x4 apre[A_PASSES];
+    auto a_load = [&](int c0) {            // input patch of one channel chunk -> registers
+        _Pragma("unroll") for (int p = 0; p < A_PASSES; ++p) {
+            const int piece = t + kThreads * p;
+            const int ch = piece & 7, pix = piece >> 3;
+            const int xh = pix % C::PW, rest = pix / C::PW;
+            const int yh = rest % C::PH, im = rest / C::PH;
+            const int gy = y_tile + yh - 1, gx = xh - 1;
+            const bool ok = piece < A_PIECES && gy >= 0 && gy < C::H && gx >= 0 && gx < C::W;
+            const int voff = ok ? int((((im * C::H + gy) * C::W + gx) * C::CIN + ch * PER) * ESZ) : int(0x7fffff00);
+            apre[p] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, voff, int(c0 * ESZ), 0);
         }
-        _Pragma("unroll") for (int p = 0; p < C::NS; ++p) {      // weights of tap 0 -> buffer 0
+    };
+    auto a_write = [&]() {
+        _Pragma("unroll") for (int p = 0; p < A_PASSES; ++p) {
+            const int piece = t + kThreads * p;
+            const int ch = piece & 7, pix = piece >> 3;
+            const int xh = pix % C::PW, rest = pix / C::PW;
+            const int yh = rest % C::PH, im = rest / C::PH;
+            if (piece < A_PIECES)
+                lds_write16(sA, ((im * C::PH + yh) * C::PW + xh) * kRowBytes + 16 * (ch ^ a_swizzle<C>(xh, im)), apre[p]);
+        }
+    };
+    u32x4 breg[C::NS];
+    auto b_load = [&](int c0, int tap) {   // one (tap, chunk) weight slice: BN rows x 128 B
+        _Pragma("unroll") for (int p = 0; p < C::NS; ++p) {
             const int piece = t + kThreads * p, n = piece >> 3, ch = piece & 7;
-            const size_t off = (size_t(n0 + n) * 9 + 0) * C::CIN + c0 + ch * PER;
-            lds_write16(sB, tile_off(n, ch), *reinterpret_cast<const u32x4*>(wgt + off));
+            breg[p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, int((n * 9 * C::CIN + ch * PER) * ESZ),
+                                                            int((tap * C::CIN + c0) * ESZ), 0);
         }
-        __syncthreads();
+    };
+    auto b_write = [&](int buf_off) {
+        _Pragma("unroll") for (int p = 0; p < C::NS; ++p) {
+            const int piece = t + kThreads * p;
+            lds_write16(sB, buf_off + tile_off(piece >> 3, piece & 7), breg[p]);
+        }
+    };
 
-        _Pragma("unroll") for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap % 3, buf = tap & 1;
-            u32x4 breg[C::NS];
-            if (tap < 8) {                    // next tap's weights: in flight behind the MFMAs
-                _Pragma("unroll") for (int p = 0; p < C::NS; ++p) {
-                    const int piece = t + kThreads * p, n = piece >> 3, ch = piece & 7;
-                    const size_t off = (size_t(n0 + n) * 9 + (tap + 1)) * C::CIN + c0 + ch * PER;
-                    breg[p] = *reinterpret_cast<const u32x4*>(wgt + off);
-                }
-            }
-            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {
-                u32x4 af[kMS], bf[C::NS];
-                _Pragma("unroll") for (int i = 0; i < kMS; ++i)
-                    af[i] = lds_read16(sA, (abase[kx] ^ (ks << 6)) + (i + ky) * C::PW * kRowBytes);
-                _Pragma("unroll") for (int j = 0; j < C::NS; ++j)
-                    bf[j] = lds_read16(sB, buf * C::B_BYTES + (bbase ^ (ks << 6)) + j * 16 * kRowBytes);
-                _Pragma("unroll") for (int i = 0; i < kMS; ++i)
-                    _Pragma("unroll") for (int j = 0; j < C::NS; ++j) mma_step<T>(af[i], bf[j], acc[i][j]);
-            }
-            if (tap < 8) {
-                _Pragma("unroll") for (int p = 0; p < C::NS; ++p) {
-                    const int piece = t + kThreads * p, n = piece >> 3, ch = piece & 7;
-                    lds_write16(sB, (buf ^ 1) * C::B_BYTES + tile_off(n, ch), breg[p]);
-                }
-            }
-            __syncthreads();
-        }
-    }
+    // prologue: first patch and first weight slice
+    a_load(0);
+    b_load(0, 0);
+    a_write();
+    b_write(0);
+    __syncthreads();
 
-    // epilogue: bias + ReLU (+ lane-local 2x2 max-pool; max commutes with the monotone bias+ReLU)
-    _Pragma("unroll") for (int j = 0; j < C::NS; ++j) {
-        const int n = n0 + (wn * C::NS + j) * 16 + r;
-        const float b = bias[n];
-        if (C::POOL) {
-            _Pragma("unroll") for (int ip = 0; ip < kMS / 2; ++ip) {
-                const f32x4 u = acc[2 * ip][j], d = acc[2 * ip + 1][j];
-                const float p0 = fmaxf(fmaxf(u.x, u.y), fmaxf(d.x, d.y));
-                const float p1 = fmaxf(fmaxf(u.z, u.w), fmaxf(d.z, d.w));
-                const int yo = (y_tile + l_y0 + 2 * ip) >> 1;
-                const int img = img0 + (C::SEGW == 8 ? (q >> 1) : 0);
-                const int xo = C::SEGW == 8 ? 2 * (q & 1) : (((C::SEGS == 2 ? wm * 16 : 0) + 4 * q) >> 1);
-                if (img < n_img) {
-                    T* o = out + ((size_t(img) * C::HO + yo) * C::WO + xo) * C::COUT + n;
-                    store_elem<T>(o, fmaxf(p0 + b, 0.f));
-                    store_elem<T>(o + C::COUT, fmaxf(p1 + b, 0.f));
+    // One barrier per tap. The weight pipeline runs continuously across channel chunks AND across
+    // tiles (slice g+1 is fetched before the MFMAs of slice g and parked in the other LDS buffer
+    // after them); the next chunk's / next tile's input patch is fetched during taps 5..8 and
+    // swapped in behind one extra barrier, so no global round trip is exposed at a boundary.
+    int par = 0;                                   // parity of the running tap counter -> current weight buffer
+    for (;;) {
+        const int next_tile = tile + int(gridDim.x);
+        const bool has_next = C::PERSIST && next_tile < n_tiles;
+        for (int c = 0; c < CHUNKS; ++c) {
+            const int c0 = c * C::KC;
+            const bool last_chunk = c + 1 == CHUNKS;
+            const bool more = !last_chunk || has_next;                       // another stage follows
+            _Pragma("unroll") for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
+                const int cur = par ? C::B_BYTES : 0;
+                if (tap < 8) b_load(c0, tap + 1);
+                else if (more) b_load(last_chunk ? 0 : c0 + C::KC, 0);
+                if (tap == 5 && more) {
+                    if (last_chunk) a_rsrc = patch_rsrc((next_tile / C::TILES_Y) * C::IMGS);
+                    a_load(last_chunk ? 0 : c0 + C::KC);
                 }
+                _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {
+                    u32x4 af[kMS], bf[C::NS];
+                    _Pragma("unroll") for (int i = 0; i < kMS; ++i)
+                        af[i] = lds_read16(sA, (abase[kx] ^ (ks << 6)) + (i + ky) * C::PW * kRowBytes);
+                    _Pragma("unroll") for (int j = 0; j < C::NS; ++j)
+                        bf[j] = lds_read16(sB, cur + (bbase ^ (ks << 6)) + j * 16 * kRowBytes);
+                    // Coarse phases: every fragment read of the k-step is issued before the first MFMA and
+                    // the MFMAs run as one burst. Left alone, hipcc re-reads two A fragments at a time with a
+                    // short LDS wait in front of every 8 MFMAs; the two waves of a SIMD then wait and compute
+                    // in lockstep (SQ_WAIT_ANY 49 %, MFMA pipe 51 % busy at the held clock).
+                    __builtin_amdgcn_sched_barrier(0);
+                    _Pragma("unroll") for (int i = 0; i < kMS; ++i)
+                        _Pragma("unroll") for (int j = 0; j < C::NS; ++j) mma_step<T>(af[i], bf[j], acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (tap < 8 || more) b_write(cur ^ C::B_BYTES);
+                __syncthreads();
+                if (tap == 8 && more) {          // every wave has finished reading the old patch
+                    a_write();
+                    __syncthreads();
+                }
+                par ^= 1;
             }
-        } else {
-            _Pragma("unroll") for (int i = 0; i < kMS; ++i) {
-                const int y = y_tile + l_y0 + i;
-                const float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) {
-                    const int rr = 4 * q + e;
-                    const int img = img0 + (C::SEGW == 8 ? (rr >> 3) : 0);
-                    const int x = C::SEGW == 8 ? (rr & 7) : ((C::SEGS == 2 ? wm * 16 : 0) + rr);
-                    if (img < n_img)
-                        store_elem<T>(out + ((size_t(img) * C::H + y) * C::W + x) * C::COUT + n, fmaxf(v[e] + b, 0.f));
+        }
+
+        // epilogue: bias + ReLU (+ lane-local 2x2 max-pool; max commutes with the monotone bias+ReLU)
+        _Pragma("unroll") for (int j = 0; j < C::NS; ++j) {
+            const int n = n0 + (wn * C::NS + j) * 16 + r;
+            const float b = bias[n];
+            if (C::POOL) {
+                _Pragma("unroll") for (int ip = 0; ip < kMS / 2; ++ip) {
+                    const f32x4 u = acc[2 * ip][j], d = acc[2 * ip + 1][j];
+                    const float p0 = fmaxf(fmaxf(u.x, u.y), fmaxf(d.x, d.y));
+                    const float p1 = fmaxf(fmaxf(u.z, u.w), fmaxf(d.z, d.w));
+                    const int yo = (y_tile + l_y0 + 2 * ip) >> 1;
+                    const int img = img0 + (C::SEGW == 8 ? (q >> 1) : 0);
+                    const int xo = C::SEGW == 8 ? 2 * (q & 1) : (((C::SEGS == 2 ? wm * 16 : 0) + 4 * q) >> 1);
+                    if (img < n_img) {
+                        T* o = out + ((size_t(img) * C::HO + yo) * C::WO + xo) * C::COUT + n;
+                        store_elem<T>(o, fmaxf(p0 + b, 0.f));
+                        store_elem<T>(o + C::COUT, fmaxf(p1 + b, 0.f));
+                    }
+                }
+            } else {
+                _Pragma("unroll") for (int i = 0; i < kMS; ++i) {
+                    const int y = y_tile + l_y0 + i;
+                    const float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {
+                        const int rr = 4 * q + e;
+                        const int img = img0 + (C::SEGW == 8 ? (rr >> 3) : 0);
+                        const int x = C::SEGW == 8 ? (rr & 7) : ((C::SEGS == 2 ? wm * 16 : 0) + rr);
+                        if (img < n_img)
+                            store_elem<T>(out + ((size_t(img) * C::H + y) * C::W + x) * C::COUT + n, fmaxf(v[e] + b, 0.f));
+                    }
                 }
             }
         }
+        if (!has_next) break;
+        tile = next_tile;
+        img0 = (tile / C::TILES_Y) * C::IMGS;
+        _Pragma("unroll") for (int i = 0; i < kMS; ++i)
+            _Pragma("unroll") for (int j = 0; j < C::NS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -269,8 +330,17 @@ int launch_conv(const void* in, const void* w, const float* bias, void* out, int
                                    C::LDS_BYTES));
     const int64_t tiles = ((n_img + C::IMGS - 1) / C::IMGS) * C::TILES_Y;
     MLA_REQUIRE(tiles <= 0x7fffffff, MLA_E_SHAPE, "too many tiles");
-    hipLaunchKernelGGL(kern, dim3(unsigned(tiles), C::COUT / C::BN), dim3(kThreads), C::LDS_BYTES, s,
-                       static_cast<const T*>(in), static_cast<const T*>(w), bias, static_cast<T*>(out), int(n_img));
+    // persistent grid: one workgroup per CU and N-tile (two where LDS/VGPRs allow), a multiple of TILES_Y
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    constexpr int n_tiles_n = C::COUT / C::BN;
+    constexpr int per_cu = (C::LDS_BYTES * 2 <= 160 * 1024 && C::MIN_WAVES >= 4) ? 2 : 1;
+    int64_t gx = int64_t(cus) * per_cu / n_tiles_n;
+    gx = gx / C::TILES_Y * C::TILES_Y;
+    if (gx < C::TILES_Y) gx = C::TILES_Y;
+    if (gx > tiles || !C::PERSIST) gx = tiles;
+    hipLaunchKernelGGL(kern, dim3(unsigned(gx), n_tiles_n), dim3(kThreads), C::LDS_BYTES, s,
+                       static_cast<const T*>(in), static_cast<const T*>(w), bias, static_cast<T*>(out), int(n_img), int(tiles));
     MLA_LAUNCH_OK("conv3x3_kernel");
     return MLA_OK;
 }

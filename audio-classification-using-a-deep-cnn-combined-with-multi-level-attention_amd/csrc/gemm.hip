@@ -32,8 +32,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 2, wn = wave & 3;
     const int r = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.x * kBM, n0 = blockIdx.y * BN;
-    const int abase = (wm * kMS * 16 + r) * kRowBytes + 16 * (q ^ ((r >> 1) & 7));
-    const int bbase = (wn * NS * 16 + r) * kRowBytes + 16 * (q ^ ((r >> 1) & 7));
+    const int abase = tile_off(wm * kMS * 16 + r, q);
+    const int bbase = tile_off(wn * NS * 16 + r, q);
 
     f32x4 acc[kMS][NS];
     _Pragma("unroll") for (int i = 0; i < kMS; ++i)

@@ -13,10 +13,13 @@
 // GEMM K order inside 16 channels is permuted (k = 4 s + q <-> channel 4 q + s) identically
 // for A and B, which leaves the sum unchanged.
 //
-// Bank conflicts: rows are 128 B, two per 256-B LDS bank row; XOR-ing the chunk index with
-// ((row >> 1) & 7) makes 16 consecutive rows read at the same logical chunk hit 16 distinct
-// 16-B slots (ds_read_b128 lane groups mix chunks q and q+1 of different rows; with an even
-// first chunk these never collide either).
+// Bank conflicts: rows are 128 B, two per 256-B LDS bank row (16 slots of 16 B). A ds_read_b128
+// lane group is {rows 0-3, 12-15 at chunk q} + {rows 4-11 at chunk q^1}: the two classes differ in
+// chunk bit 0, so the swizzle leaves bit 0 alone and XORs bits 1-2 with (row >> 1) & 3. Inside a
+// class the 8 rows are two runs of 4 that are 12 apart = consecutive mod 8, so (row & 1, (row>>1)&3)
+// are 8 distinct slot pairs for ANY starting row -- i.e. also for the kx-shifted taps of the
+// convolution (a swizzle on all three bits is conflict-free only for unshifted reads; measured
+// 22 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE before this fix).
 #ifndef MLA_MMA_CORE_H
 #define MLA_MMA_CORE_H
 
@@ -74,7 +77,7 @@ __device__ __forceinline__ u32x4 zero16() { return u32x4{0u, 0u, 0u, 0u}; }
 
 // byte offset of (row, chunk) in a plain [rows][128 B] tile with the XOR swizzle
 __device__ __forceinline__ int tile_off(int row, int chunk) {
-    return row * kRowBytes + 16 * (chunk ^ ((row >> 1) & 7));
+    return row * kRowBytes + 16 * (chunk ^ (((row >> 1) & 3) << 1));
 }
 
 }  // namespace mma
