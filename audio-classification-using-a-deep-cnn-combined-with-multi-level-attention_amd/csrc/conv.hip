@@ -258,17 +258,24 @@ template <typename TIN, typename T>
 __global__ __launch_bounds__(256) void conv1_kernel(const TIN* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ bias, T* __restrict__ out,
                                                     int64_t n_pix) {
-    const int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (idx >= n_pix) return;
+    // Each wave owns 64 consecutive pooled pixels = one contiguous 64 x 64-channel block of the NHWC
+    // output. Results are parked in LDS ([pixel][64 ch], rows padded by 16 B) and leave as 1 KiB-
+    // contiguous wave stores; storing 16 B per lane at the 128-B pixel stride ran at 1.7 TB/s.
+    constexpr int ROW = 64 * int(sizeof(T)) + 16;              // bytes per pixel row in LDS
+    __shared__ __attribute__((aligned(16))) char stage[4][64 * ROW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t pix0 = (int64_t(blockIdx.x) * 4 + wave) * 64;
+    const int64_t idx = pix0 + lane;
+    const bool live = idx < n_pix;
     const int px = int(idx & 31), py = int((idx >> 5) % 48);
     const int64_t n = idx / (48 * 32);
     float patch[4][4];
     _Pragma("unroll") for (int a = 0; a < 4; ++a)
         _Pragma("unroll") for (int b = 0; b < 4; ++b) {
             const int iy = 2 * py - 1 + a, ix = 2 * px - 1 + b;
-            patch[a][b] = (iy >= 0 && iy < 96 && ix >= 0 && ix < 64) ? load_elem<TIN>(x + (n * 96 + iy) * 64 + ix) : 0.f;
+            patch[a][b] = (live && iy >= 0 && iy < 96 && ix >= 0 && ix < 64) ? load_elem<TIN>(x + (n * 96 + iy) * 64 + ix) : 0.f;
         }
-    T* o = out + idx * 64;
+    char* mine = stage[wave] + lane * ROW;
     for (int cg = 0; cg < 8; ++cg) {
         float res[8];
         _Pragma("unroll") for (int c = 0; c < 8; ++c) {
@@ -290,11 +297,23 @@ __global__ __launch_bounds__(256) void conv1_kernel(const TIN* __restrict__ x, c
             pk.y = f2bf(res[2]) | (uint32_t(f2bf(res[3])) << 16);
             pk.z = f2bf(res[4]) | (uint32_t(f2bf(res[5])) << 16);
             pk.w = f2bf(res[6]) | (uint32_t(f2bf(res[7])) << 16);
-            *reinterpret_cast<u32x4*>(o + cg * 8) = pk;
+            *reinterpret_cast<u32x4*>(mine + cg * 16) = pk;
         } else {
-            *reinterpret_cast<f32x4*>(o + cg * 8) = f32x4{res[0], res[1], res[2], res[3]};
-            *reinterpret_cast<f32x4*>(o + cg * 8 + 4) = f32x4{res[4], res[5], res[6], res[7]};
+            *reinterpret_cast<f32x4*>(mine + cg * 32) = f32x4{res[0], res[1], res[2], res[3]};
+            *reinterpret_cast<f32x4*>(mine + cg * 32 + 16) = f32x4{res[4], res[5], res[6], res[7]};
         }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the block is private to this wave:
+    __builtin_amdgcn_wave_barrier();                            // LDS ops of one wave execute in order
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int PIECES = 64 * int(sizeof(T)) / 16;            // 16-B pieces per pixel: 8 (bf16) or 16 (f32)
+    char* dst = reinterpret_cast<char*>(out + pix0 * 64);
+    const int64_t valid = (n_pix - pix0 < 64 ? n_pix - pix0 : 64) * PIECES;
+    _Pragma("unroll") for (int it = 0; it < PIECES; ++it) {
+        const int piece = it * 64 + lane;                      // linear 16-B piece of the 64-pixel block
+        const int p = piece / PIECES, c = piece % PIECES;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stage[wave] + p * ROW + c * 16);
+        if (piece < valid) *reinterpret_cast<u32x4*>(dst + size_t(piece) * 16) = v;
     }
 }
 
@@ -403,7 +422,7 @@ extern "C" int mla_vggish_conv1(const void* x, int x_dtype, int64_t n, const flo
     MLA_REQUIRE((x_dtype == MLA_F32 || x_dtype == MLA_BF16) && (dtype == MLA_F32 || dtype == MLA_BF16), MLA_E_DTYPE,
                 "conv1 dtypes %d -> %d", x_dtype, dtype);
     const int64_t n_pix = n * 48 * 32;
-    const int64_t blocks = (n_pix + 255) / 256;
+    const int64_t blocks = (n_pix + 255) / 256;                 // 4 waves x 64 pooled pixels per workgroup
     MLA_REQUIRE(blocks <= 0x7fffffff, MLA_E_SHAPE, "batch too large");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 g{unsigned(blocks)}, b{256};

@@ -78,8 +78,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
                 af[i] = lds_read16(sA, buf * A_BYTES + (abase ^ (ks << 6)) + i * 16 * kRowBytes);
             _Pragma("unroll") for (int j = 0; j < NS; ++j)
                 bf[j] = lds_read16(sB, buf * B_BYTES + (bbase ^ (ks << 6)) + j * 16 * kRowBytes);
+            __builtin_amdgcn_sched_barrier(0);     // coarse phases: all reads, then one MFMA burst (see conv.hip)
             _Pragma("unroll") for (int i = 0; i < kMS; ++i)
                 _Pragma("unroll") for (int j = 0; j < NS; ++j) mma_step<T>(af[i], bf[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (s + 1 < stages) lwrite(buf ^ 1);   // the other buffer was last read before the previous barrier
         __syncthreads();

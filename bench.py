@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--bags", type=int, default=1024, help="bags (10 s waveforms) per GPU per step")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse N>1 on one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,12 +108,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    local_rank %= max(torch.cuda.device_count(), 1)          # rehearsal on fewer GPUs than ranks (gloo only)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     importlib.import_module(PKG + ".build").build(verbose=False) if rank == 0 and not os.path.exists(
         os.path.join(ROOT, PKG, "libmla_hip.so")) else None
@@ -140,7 +145,7 @@ def main():
         prof, ops.profile = ops.profile, None
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
