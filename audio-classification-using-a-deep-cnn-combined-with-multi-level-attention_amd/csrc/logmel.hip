@@ -30,8 +30,9 @@ constexpr int kChunk = 32;                                // STFT frames per chu
 constexpr int kThreads = 256;
 constexpr int kSpan = (kChunk - 1) * kHop + kWin;         // 5360 samples per chunk
 constexpr int kXchFloats = 2 * 16 * kXchStride;           // 544 per 16-lane group
-constexpr int kLdsFloats = kSpan + 16 * kXchFloats + 16 * 256 + 16 * kBands + kLaneTabFloats;
-constexpr int kLdsBytes = kLdsFloats * 4;                 // 80 320 B -> 2 workgroups per CU
+constexpr int kMagStride = 256 + 16;                      // +16 floats: the two frames of a 32-lane half land on different bank halves
+constexpr int kLdsFloats = kSpan + 16 * kXchFloats + 16 * kMagStride + 16 * kBands + kLaneTabFloats;
+constexpr int kLdsBytes = kLdsFloats * 4;                 // 81 600 B -> 2 workgroups per CU
 static_assert(2 * kLdsBytes <= 160 * 1024, "two workgroups must fit one CU's LDS");
 constexpr int kStageVec = (kSpan / 4 + kThreads - 1) / kThreads;   // 6 float4 per thread
 
@@ -140,12 +141,12 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const InT* __restri
     float* s_pcm = smem;
     float* s_xch = s_pcm + kSpan;
     float* s_mag = s_xch + 16 * kXchFloats;
-    float* s_row = s_mag + 16 * 256;
+    float* s_row = s_mag + 16 * kMagStride;
     float* s_tab = s_row + 16 * kBands;      // per-lane mel weights + split twiddles (3.5 KB)
 
     const int t = threadIdx.x, g = t >> 4, j = t & 15;
     float* xg = s_xch + g * kXchFloats;
-    float* mg = s_mag + g * 256;
+    float* mg = s_mag + g * kMagStride;
 
     LaneConsts c;
     load_consts(c, tab, j);

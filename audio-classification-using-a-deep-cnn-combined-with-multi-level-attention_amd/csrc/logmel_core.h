@@ -42,7 +42,7 @@ constexpr int kTabWindow = 0;              // 512 floats: Hann(400) then zeros
 constexpr int kTabTw256 = 512;             // 256 x (cos, -sin)(2 pi m / 256)
 constexpr int kTabTw512 = 1024;            // 129 x (cos, -sin)(2 pi k / 512), padded to 512
 constexpr int kTabMelStart = 1536;         // 16 lanes x 4 slots, int32 first bin of the slot
-constexpr int kMelRow = 40;                // padded per-lane weight row (16-byte multiples)
+constexpr int kMelRow = 44;                // padded per-lane weight row: 44 j mod 64 banks distinct for ds_read_b128
 constexpr int kPwRow = 16;                 // per-lane split twiddles: 8 x (re, im)
 constexpr int kTabMelW = 1600;             // 16 lanes x kMelRow floats, weights / 2 (zero padded)
 constexpr int kTabPw = kTabMelW + 16 * kMelRow;     // 16 lanes x kPwRow: w^(1 + j + 16 i)
@@ -179,7 +179,7 @@ MLA_HD void phase2_write(int j, float* re, float* im, float* zbuf) {
 
 MLA_HD float fast_sqrt(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_sqrtf(v);
+    return __builtin_amdgcn_sqrtf(v);      // one v_sqrt_f32 (~1 ulp); sqrtf() expands to ~12 VALU of fix-ups
 #else
     return __builtin_sqrtf(v);
 #endif
@@ -210,7 +210,11 @@ MLA_HD void phase4(const LaneConsts& c, int j, const float* mag, const float* me
         const float* m = mag + c.mel_start[s];
         float acc = 0.f;
         _Pragma("unroll") for (int t = 0; t < count[s]; ++t) acc += melw[first[s] + t] * m[t];
+#if defined(__HIP_DEVICE_COMPILE__)
+        out4[s] = __builtin_amdgcn_logf(acc + 0.01f) * 0.69314718055994530942f;   // v_log_f32 (log2) * ln 2; argument >= 0.01
+#else
         out4[s] = __builtin_logf(acc + 0.01f);
+#endif
     }
 }
 

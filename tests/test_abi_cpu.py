@@ -68,7 +68,7 @@ def test_tables_match_oracle(L):
     np.testing.assert_allclose(tab[513:1024:2], -np.sin(2 * np.pi * m / 256), atol=1e-7)
     # sparse per-lane mel rows reproduce the dense matrix (weights are stored halved)
     starts = tab[1536:1600].view(np.int32).reshape(16, 4)
-    rows = tab[1600:1600 + 16 * 40].reshape(16, 40)
+    rows = tab[1600:1600 + 16 * 44].reshape(16, 44)
     dense = np.zeros((257, 64))
     counts = (4, 6, 10, 17)
     for lane in range(16):
