@@ -47,6 +47,8 @@ def lib():
         L.mla_logmel_reference_tables.argtypes = [vp, vp]
         L.mla_logmel_examples.argtypes = [vp, ci, i64, i64, i64, vp, vp, ci, vp]
         cf = ctypes.c_float
+        L.mla_stft_magnitude.argtypes = [vp, i64, vp, vp, i64, i64, i64, vp, vp]
+        L.mla_mel_log.argtypes = [vp, vp, i64, i64, i64, cf, vp, vp]
         L.mla_conv_repack_weights.argtypes = [vp, i64, i64, vp, ci, vp]
         L.mla_convert_f32.argtypes = [vp, vp, i64, ci, vp]
         L.mla_convert_bf16_to_f32.argtypes = [vp, vp, i64, vp]

@@ -1,0 +1,90 @@
+// stft_generic.hip -- stand-alone mel_features.stft_magnitude / log_mel_spectrogram for ARBITRARY
+// configurations (reference API: mel_features.py:71-92 and :192-223 accept any window / hop /
+// power-of-two FFT length / mel layout). The VGGish configuration on the hot path is served by the
+// fused kernel in logmel.hip; these kernels exist so that the drop-in module keeps the reference's
+// full argument space on the GPU. They are simple (one workgroup per frame, radix-2 FFT in LDS,
+// dense mel product) and not tuned.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxFft = 4096;
+
+// One workgroup per STFT frame: x[frame*hop + n] * window[n] (n < win), zero-padded to `fft`,
+// in-place iterative radix-2 decimation-in-time FFT on (re, im) in LDS, then |X[k]|, k <= fft/2.
+// twiddle: fft/2 pairs (cos, -sin)(2 pi m / fft) computed on the host in double precision.
+__global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ signal, const float* __restrict__ window,
+                                                   const float* __restrict__ twiddle, int win, int hop, int fft, int log2fft,
+                                                   float* __restrict__ out) {
+    extern __shared__ float lds[];
+    float* re = lds;
+    float* im = lds + fft;
+    const int64_t frame = blockIdx.x;
+    const float* x = signal + frame * hop;
+    for (int n = threadIdx.x; n < fft; n += 256) {
+        const unsigned rev = __brev(unsigned(n)) >> (32 - log2fft);       // bit-reversed load position
+        re[rev] = n < win ? x[n] * window[n] : 0.f;
+        im[rev] = 0.f;
+    }
+    __syncthreads();
+    for (int s = 1; s <= log2fft; ++s) {
+        const int half = 1 << (s - 1), step = fft >> s;                    // twiddle index stride
+        for (int b = threadIdx.x; b < fft / 2; b += 256) {
+            const int grp = b / half, pos = b % half;
+            const int i0 = grp * 2 * half + pos, i1 = i0 + half;
+            const float wr = twiddle[2 * (pos * step)], wi = twiddle[2 * (pos * step) + 1];
+            const float tr = re[i1] * wr - im[i1] * wi, ti = re[i1] * wi + im[i1] * wr;
+            const float ur = re[i0], ui = im[i0];
+            re[i0] = ur + tr; im[i0] = ui + ti;
+            re[i1] = ur - tr; im[i1] = ui - ti;
+        }
+        __syncthreads();
+    }
+    const int bins = fft / 2 + 1;
+    for (int k = threadIdx.x; k < bins; k += 256) out[frame * bins + k] = sqrtf(re[k] * re[k] + im[k] * im[k]);
+}
+
+// out[f][b] = log(sum_k spec[f][k] * mel[k][b] + offset)      (mel_features.py:220-223)
+__global__ __launch_bounds__(256) void mel_log_kernel(const float* __restrict__ spec, const float* __restrict__ mel, int64_t frames,
+                                                      int bins, int bands, float offset, float* __restrict__ out) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= frames * bands) return;
+    const int64_t f = i / bands;
+    const int b = int(i - f * bands);
+    float acc = 0.f;
+    for (int k = 0; k < bins; ++k) acc = fmaf(spec[f * bins + k], mel[int64_t(k) * bands + b], acc);
+    out[i] = logf(acc + offset);
+}
+
+}  // namespace
+
+// mel_features.stft_magnitude for one 1-D signal: frames = 1 + floor((n - win)/hop) rows of fft/2+1 magnitudes.
+extern "C" int mla_stft_magnitude(const float* signal, int64_t n_samples, const float* window, const float* twiddle,
+                                  int64_t window_length, int64_t hop_length, int64_t fft_length, float* out,
+                                  mla_stream_t stream) {
+    MLA_REQUIRE(signal && window && twiddle && out, MLA_E_ARG, "null stft argument");
+    MLA_REQUIRE(window_length >= 1 && hop_length >= 1 && fft_length >= window_length && fft_length <= kMaxFft &&
+                    (fft_length & (fft_length - 1)) == 0 && fft_length >= 2,
+                MLA_E_SHAPE, "stft needs a power-of-two fft_length in [max(2, window), %d] (got window %lld, fft %lld)", kMaxFft,
+                (long long)window_length, (long long)fft_length);
+    if (n_samples < window_length) return MLA_OK;          // zero frames (the caller sized `out` accordingly)
+    const int64_t frames = 1 + (n_samples - window_length) / hop_length;
+    MLA_REQUIRE(frames <= 0x7fffffff, MLA_E_SHAPE, "too many frames");
+    int lg = 0;
+    while ((1ll << lg) < fft_length) ++lg;
+    hipLaunchKernelGGL(stft_kernel, dim3(unsigned(frames)), dim3(256), size_t(2 * fft_length * sizeof(float)),
+                       static_cast<hipStream_t>(stream), signal, window, twiddle, int(window_length), int(hop_length),
+                       int(fft_length), lg, out);
+    MLA_LAUNCH_OK("stft_kernel");
+    return MLA_OK;
+}
+
+extern "C" int mla_mel_log(const float* spectrogram, const float* mel_matrix, int64_t frames, int64_t bins, int64_t bands,
+                           float log_offset, float* out, mla_stream_t stream) {
+    MLA_REQUIRE(spectrogram && mel_matrix && out && frames >= 0 && bins >= 1 && bands >= 1, MLA_E_ARG, "bad mel_log arguments");
+    if (frames == 0) return MLA_OK;
+    hipLaunchKernelGGL(mel_log_kernel, dim3(unsigned((frames * bands + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), spectrogram, mel_matrix, frames, int(bins), int(bands), log_offset, out);
+    MLA_LAUNCH_OK("mel_log_kernel");
+    return MLA_OK;
+}

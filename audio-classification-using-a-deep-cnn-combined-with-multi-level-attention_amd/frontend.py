@@ -85,9 +85,49 @@ def waveforms_to_examples(pcm, out_dtype=torch.float32, out=None):
     return out
 
 
+def _as_device_signal(signal):
+    dev = _device()
+    if isinstance(signal, np.ndarray):
+        return torch.from_numpy(np.ascontiguousarray(signal.astype(np.float32))).to(dev)
+    return signal.to(dev).float().contiguous()
+
+
 def stft_magnitude(signal, fft_length, hop_length, window_length):
-    raise NotImplementedError("stand-alone stft_magnitude kernel not built yet")
+    """mel_features.stft_magnitude (mel_features.py:71-92) on the GPU for any window / hop and
+    power-of-two fft_length <= 4096: (frames, fft_length/2 + 1) float32 CUDA tensor."""
+    from .torchvggish import mel_features
+    x = _as_device_signal(signal)
+    assert x.dim() == 1
+    n = x.shape[0]
+    frames = 1 + int(np.floor((n - window_length) / hop_length))
+    if frames < 0:
+        raise ValueError("negative dimensions are not allowed")
+    bins = fft_length // 2 + 1
+    out = torch.empty((frames, bins), dtype=torch.float32, device=x.device)
+    if frames == 0:
+        return out
+    window = torch.from_numpy(mel_features.periodic_hann(window_length).astype(np.float32)).to(x.device)
+    m = np.arange(fft_length // 2)
+    tw = np.stack([np.cos(2 * np.pi * m / fft_length), -np.sin(2 * np.pi * m / fft_length)], axis=1).astype(np.float32)
+    tw = torch.from_numpy(np.ascontiguousarray(tw)).to(x.device)
+    vp = ctypes.c_void_p
+    _lib.check(_lib.lib().mla_stft_magnitude(vp(x.data_ptr()), n, vp(window.data_ptr()), vp(tw.data_ptr()), int(window_length),
+                                             int(hop_length), int(fft_length), vp(out.data_ptr()), _lib.stream_ptr()))
+    return out
 
 
 def log_mel_spectrogram(data, audio_sample_rate, log_offset, window_length_secs, hop_length_secs, **kwargs):
-    raise NotImplementedError("stand-alone log_mel_spectrogram kernel not built yet")
+    """mel_features.log_mel_spectrogram (mel_features.py:192-223) on the GPU for any configuration:
+    (frames, num_mel_bins) float32 CUDA tensor. The mel matrix is host-side setup, as in the reference."""
+    from .torchvggish import mel_features
+    win = int(round(audio_sample_rate * window_length_secs))
+    hop = int(round(audio_sample_rate * hop_length_secs))
+    fft = 2 ** int(np.ceil(np.log(win) / np.log(2.0)))
+    spec = stft_magnitude(data, fft, hop, win)
+    mel = mel_features.spectrogram_to_mel_matrix(num_spectrogram_bins=spec.shape[1], audio_sample_rate=audio_sample_rate, **kwargs)
+    melt = torch.from_numpy(np.ascontiguousarray(mel.astype(np.float32))).to(spec.device)
+    out = torch.empty((spec.shape[0], mel.shape[1]), dtype=torch.float32, device=spec.device)
+    vp = ctypes.c_void_p
+    _lib.check(_lib.lib().mla_mel_log(vp(spec.data_ptr()), vp(melt.data_ptr()), spec.shape[0], spec.shape[1], mel.shape[1],
+                                      float(log_offset), vp(out.data_ptr()), _lib.stream_ptr()))
+    return out

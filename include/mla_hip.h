@@ -79,6 +79,21 @@ int mla_logmel_examples(const void* pcm, int pcm_dtype, int64_t n_wave, int64_t 
                         int64_t wave_stride, const float* tables, void* out, int out_dtype,
                         mla_stream_t stream);
 
+/* Stand-alone stages for ARBITRARY configurations of the reference API (any window / hop /
+ * power-of-two fft_length <= 4096, any mel layout); the VGGish configuration on the hot path
+ * uses mla_logmel_examples instead.
+ * mla_stft_magnitude: mel_features.stft_magnitude (mel_features.py:71-92) of one 1-D f32 signal;
+ *   window: window_length floats (host-built periodic Hann); twiddle: fft_length/2 pairs
+ *   (cos, -sin)(2 pi m / fft_length); out: frames x (fft_length/2 + 1) magnitudes,
+ *   frames = 1 + floor((n_samples - window_length) / hop_length) (none if the signal is shorter).
+ * mla_mel_log: log(spectrogram . mel_matrix + log_offset) (mel_features.py:220-223);
+ *   spectrogram frames x bins, mel_matrix bins x bands (row-major), out frames x bands. */
+int mla_stft_magnitude(const float* signal, int64_t n_samples, const float* window, const float* twiddle,
+                       int64_t window_length, int64_t hop_length, int64_t fft_length, float* out,
+                       mla_stream_t stream);
+int mla_mel_log(const float* spectrogram, const float* mel_matrix, int64_t frames, int64_t bins, int64_t bands,
+                float log_offset, float* out, mla_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * VGGish feature stack: torchvggish/vggish.py:108-118 (make_layers) applied at :22.
  * Activations are NHWC (N, H, W, C) in the compute dtype (MLA_BF16 or MLA_F32); this

@@ -120,3 +120,35 @@ def test_full_size_properties(fe, W):
     assert torch.equal(shifted.view(8, 10, 96, 64)[:, :9], first.view(8, 10, 96, 64)[:, 1:])
     ref = ofe.batch_examples(base[:1, :n].cpu().numpy().astype(np.float64))
     assert np.abs(first[:10].cpu().numpy() - ref).max() <= 1e-4
+
+
+def test_standalone_stft_and_logmel_any_configuration(golden, mk, W):
+    """mel_features.stft_magnitude / log_mel_spectrogram keep the reference's whole argument space
+    (generic kernels); checked against reference-generated rows and against the oracle."""
+    mf = importlib.import_module(PKG + ".torchvggish.mel_features")
+    g = golden("frontend")
+    noise = mk.test_waveforms()["noise_30960"]
+    spec = mf.stft_magnitude(noise, fft_length=512, hop_length=160, window_length=400)
+    assert spec.is_cuda and tuple(spec.shape) == tuple(g["stft_shape/noise_30960"])
+    ref_rows = g["stft_rows/noise_30960"]
+    got_rows = spec[[0, 1, 95, 96, 190]].cpu().numpy()
+    assert np.abs(got_rows - ref_rows).max() <= 2e-5 * np.abs(ref_rows).max()
+    lm = mf.log_mel_spectrogram(noise, audio_sample_rate=16000, log_offset=0.01, window_length_secs=0.025,
+                                hop_length_secs=0.010, num_mel_bins=64, lower_edge_hertz=125, upper_edge_hertz=7500)
+    assert tuple(lm.shape) == tuple(g["logmel_shape/noise_30960"])
+    assert np.abs(lm[-3:].cpu().numpy() - g["logmel_tail/noise_30960"]).max() <= 1e-4
+    x8 = W.uniform(15, W.stream_id("noise8k_4000"), 4000, dtype=np.float64)
+    lm8 = mf.log_mel_spectrogram(x8)                                   # 8 kHz defaults: window 200, fft 256, 20 bands, offset 0
+    ref8 = g["logmel_default8k/noise8k_4000"]
+    assert tuple(lm8.shape) == ref8.shape and np.abs(lm8.cpu().numpy() - ref8).max() <= 1e-4
+    for fft, win, hop in ((64, 50, 7), (2048, 1500, 333), (4096, 4096, 4096)):
+        sig = W.uniform(16, fft, 3 * fft + 11, dtype=np.float64)
+        ref = ofe.stft_magnitude(sig, fft, hop, win)
+        got = mf.stft_magnitude(sig, fft, hop, win).cpu().numpy()
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 3e-5 * np.abs(ref).max()
+    with pytest.raises(ValueError):
+        mf.stft_magnitude(np.zeros(10), 512, 160, 400 + 160 * 2)
+    with pytest.raises(ValueError):
+        mf.spectrogram_to_mel_matrix(upper_edge_hertz=5000.0)
+    assert mf.frame(torch.arange(10).cuda(), 4, 3).tolist() == [[0, 1, 2, 3], [3, 4, 5, 6], [6, 7, 8, 9]]
+    assert np.array_equal(mf.frame(np.arange(10), 4, 3), ofe.frame(np.arange(10), 4, 3))
