@@ -31,11 +31,12 @@ using namespace mma;
 
 constexpr int kThreads = 512, kWavesN = 4, kMS = 6;
 
-template <typename T, int CIN_, int COUT_, int H_, int W_, bool POOL_, int NS_>
+template <typename T, int CIN_, int COUT_, int H_, int W_, bool POOL_, int NS_, bool ACT_ = true>
 struct Cfg {
     using elem = T;
     static constexpr int CIN = CIN_, COUT = COUT_, H = H_, W = W_, NS = NS_;
     static constexpr bool POOL = POOL_;
+    static constexpr bool ACT = ACT_;                       // epilogue: bias + ReLU (forward) or plain store (dgrad)
     static constexpr int SEGW = W >= 16 ? 16 : 8;          // pixels of one image row per m-subtile
     static constexpr int SEGS = W / SEGW;                   // subtiles per tile row (2 for W = 32)
     static constexpr int IMGS = 16 / SEGW;                  // images per tile (2 for W = 8)
@@ -47,7 +48,7 @@ struct Cfg {
     static constexpr int B_BYTES = BN * kRowBytes;
     static constexpr int LDS_BYTES = A_BYTES + 2 * B_BYTES;
     static constexpr int TILES_Y = H / TH;
-    static constexpr bool PERSIST = NS != 2;                // conv2 (half-width tile): two non-persistent workgroups per CU
+    static constexpr bool PERSIST = NS > 2;                 // conv2 (half-width tile): two non-persistent workgroups per CU
     static constexpr int MIN_WAVES = (PERSIST || sizeof(T) == 4) ? 2 : 4;      // waves per SIMD the register budget is held to
     static constexpr int HO = POOL ? H / 2 : H, WO = POOL ? W / 2 : W;
     static_assert(W == 32 || W == 16 || W == 8, "tile mapping covers the VGGish widths");
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                         const int img = img0 + (C::SEGW == 8 ? (rr >> 3) : 0);
                         const int x = C::SEGW == 8 ? (rr & 7) : ((C::SEGS == 2 ? wm * 16 : 0) + rr);
                         if (img < n_img)
-                            store_elem<T>(out + ((size_t(img) * C::H + y) * C::W + x) * C::COUT + n, fmaxf(v[e] + b, 0.f));
+                            store_elem<T>(out + ((size_t(img) * C::H + y) * C::W + x) * C::COUT + n, C::ACT ? fmaxf(v[e] + b, 0.f) : v[e]);
                     }
                 }
             }
@@ -376,7 +377,62 @@ int conv_layer(int layer, const void* in, const void* w, const float* bias, void
     return mla::fail(MLA_E_SHAPE, "conv layer %d is not one of VGGish conv2..conv6", layer);
 }
 
+// (Cout, Cin, 3, 3) f32 -> (Cin, 9, Cout) with the taps flipped: the weights of the transposed
+// convolution that maps dZ (N,H,W,Cout) to dA (N,H,W,Cin):  W'[ci][8 - tap][co] = W[co][ci][tap]
+__global__ void repack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin) {
+    const int64_t total = int64_t(cout) * 9 * cin;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+        const int co = int(i % cout);
+        const int tap = int((i / cout) % 9);
+        const int ci = int(i / (int64_t(cout) * 9));
+        out[i] = w[(int64_t(co) * cin + ci) * 9 + (8 - tap)];
+    }
+}
+
+// every compiled (H, W, Cin, Cout, pool, act) combination in f32: VGGish forward without the fused
+// pool (training keeps the pre-pool activations) and the five dgrad shapes
+int conv_generic_f32(const void* in, const void* w, const float* bias, void* out, int64_t n, int H, int W, int cin, int cout,
+                     bool pool, bool act, hipStream_t s) {
+#define MLA_CONV_CASE(CI, CO, HH, WW, PO, NS_, AC)                                                             \
+    if (cin == CI && cout == CO && H == HH && W == WW && pool == PO && act == AC)                              \
+        return launch_conv<Cfg<float, CI, CO, HH, WW, PO, NS_, AC>>(in, w, bias, out, n, s);
+    MLA_CONV_CASE(64, 128, 48, 32, true, 2, true)
+    MLA_CONV_CASE(128, 256, 24, 16, false, 4, true)
+    MLA_CONV_CASE(256, 256, 24, 16, true, 4, true)
+    MLA_CONV_CASE(256, 512, 12, 8, false, 4, true)
+    MLA_CONV_CASE(512, 512, 12, 8, true, 4, true)
+    MLA_CONV_CASE(64, 128, 48, 32, false, 2, true)        // training forward: pre-pool activations kept
+    MLA_CONV_CASE(256, 256, 24, 16, false, 4, true)
+    MLA_CONV_CASE(512, 512, 12, 8, false, 4, true)
+    MLA_CONV_CASE(512, 512, 12, 8, false, 4, false)       // dgrad conv6
+    MLA_CONV_CASE(512, 256, 12, 8, false, 4, false)       // dgrad conv5
+    MLA_CONV_CASE(256, 256, 24, 16, false, 4, false)      // dgrad conv4
+    MLA_CONV_CASE(256, 128, 24, 16, false, 2, false)      // dgrad conv3
+    MLA_CONV_CASE(128, 64, 48, 32, false, 1, false)       // dgrad conv2
+#undef MLA_CONV_CASE
+    return mla::fail(MLA_E_SHAPE, "conv3x3 %dx%d %d->%d pool=%d act=%d is not compiled", H, W, cin, cout, int(pool), int(act));
+}
+
 }  // namespace
+
+extern "C" int mla_conv3x3(const void* in, const void* w_packed, const float* bias, void* out, int64_t n, int H, int W,
+                           int cin, int cout, int pool, int act, int dtype, mla_stream_t stream) {
+    MLA_REQUIRE(n >= 0, MLA_E_ARG, "n %lld", (long long)n);
+    if (n == 0) return MLA_OK;
+    MLA_REQUIRE(in && w_packed && out && (bias || !act), MLA_E_ARG, "null conv buffers");
+    MLA_REQUIRE(mla::aligned(in, 16) && mla::aligned(w_packed, 16), MLA_E_ARG, "conv buffers must be 16-byte aligned");
+    MLA_REQUIRE(dtype == MLA_F32, MLA_E_DTYPE, "the generic conv entry (training / dgrad) is compiled for f32 only");
+    return conv_generic_f32(in, w_packed, bias, out, n, H, W, cin, cout, pool != 0, act != 0, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mla_conv_repack_dgrad(const float* w_oihw, int64_t cout, int64_t cin, float* out, mla_stream_t stream) {
+    MLA_REQUIRE(w_oihw && out && cout > 0 && cin > 0, MLA_E_ARG, "bad repack arguments");
+    const int64_t total = cout * 9 * cin;
+    const unsigned grid = unsigned((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(repack_dgrad_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), w_oihw, out, int(cout), int(cin));
+    MLA_LAUNCH_OK("repack_dgrad_kernel");
+    return MLA_OK;
+}
 
 extern "C" int mla_conv_repack_weights(const float* w_oihw, int64_t cout, int64_t cin, void* out, int dtype,
                                        mla_stream_t stream) {

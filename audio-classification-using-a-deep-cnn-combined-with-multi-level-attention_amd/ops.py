@@ -266,8 +266,10 @@ def transpose_padded(x):
 def col_sum(x, out):
     _chk(x, torch.float32)
     rows, cols = x.shape
-    ws = _workspace(x.device)
-    assert 64 * cols <= ws.numel()
+    key = "colsum/" + str(x.device)
+    if key not in _ws or _ws[key].numel() < 64 * cols:
+        _ws[key] = torch.empty(64 * max(cols, 4096), dtype=torch.float64, device=x.device)
+    ws = _ws[key]
     _lib.check(_lib.lib().mla_col_sum(_p(x), x.stride(0), rows, cols, _p(ws), _p(out), _lib.stream_ptr()))
     return out
 
@@ -292,3 +294,65 @@ def cross_entropy(scores, labels, inv_total, want_grad=True):
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
     _lib.check(_lib.lib().mla_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
                                         int(step), _lib.stream_ptr()))
+
+
+# ------------------------------------------------------------------ finetune (CNN gradients) ----
+
+def conv3x3(x, w_packed, b, cout, pool, act):
+    """Generic f32 conv entry (training forward without fused pool, and dgrad). x NHWC."""
+    _chk(x, torch.float32); _chk(w_packed, torch.float32)
+    n, H, W_, cin = x.shape
+    out = torch.empty((n, H // 2, W_ // 2, cout) if pool else (n, H, W_, cout), dtype=torch.float32, device=x.device)
+    _lib.check(_timed("conv3x3_%d_%d" % (cin, cout), _lib.lib().mla_conv3x3, _p(x), _p(w_packed), _p(b), _p(out), n, H, W_, cin, cout,
+                      int(pool), int(act), _lib.F32, _lib.stream_ptr()))
+    return out
+
+
+def repack_dgrad(w):
+    """(Cout, Cin, 3, 3) -> (Cin, 9, Cout) flipped: weights of the transposed convolution."""
+    _chk(w, torch.float32)
+    cout, cin = w.shape[0], w.shape[1]
+    out = torch.empty((cin, 9, cout), dtype=torch.float32, device=w.device)
+    _lib.check(_lib.lib().mla_conv_repack_dgrad(_p(w), cout, cin, _p(out), _lib.stream_ptr()))
+    return out
+
+
+def maxpool2x2(a):
+    _chk(a, torch.float32)
+    n, H, W_, C = a.shape
+    out = torch.empty((n, H // 2, W_ // 2, C), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().mla_maxpool2x2(_p(a), _p(out), n, H, W_, C, _lib.stream_ptr()))
+    return out
+
+
+def relu_pool_bwd(a, d_out, pool):
+    """dZ at a's resolution from the gradient of relu(.) [pool == 0] or maxpool(relu(.)) [pool == 1]."""
+    _chk(a, torch.float32); _chk(d_out, torch.float32)
+    a4 = a if a.dim() == 4 else a.reshape(a.shape[0], 1, 1, -1)
+    n, H, W_, C = a4.shape
+    dz = torch.empty_like(a)
+    _lib.check(_lib.lib().mla_relu_pool_bwd(_p(a), _p(d_out), _p(dz), n, H, W_, C, int(pool), _lib.stream_ptr()))
+    return dz
+
+
+_wg_ws = {}
+
+
+def conv_wgrad(dz, a_in, dw):
+    _chk(dz, torch.float32); _chk(a_in, torch.float32)
+    n, H, W_, cout = dz.shape
+    cin = a_in.shape[3]
+    key = str(dz.device)
+    if key not in _wg_ws:
+        _wg_ws[key] = torch.empty(int(_lib.lib().mla_conv_wgrad_workspace_floats()), dtype=torch.float32, device=dz.device)
+    ws = _wg_ws[key]
+    assert dw.is_contiguous() and tuple(dw.shape) == (cout, cin, 3, 3)
+    _lib.check(_timed("wgrad_%d_%d" % (cin, cout), _lib.lib().mla_conv_wgrad, _p(dz), _p(a_in), n, H, W_, cin, cout, _p(ws), ws.numel(),
+                      _p(dw), _lib.stream_ptr()))
+
+
+def conv1_bwd(x, w, b, d_pooled, dw, db):
+    _chk(x, torch.float32); _chk(d_pooled, torch.float32)
+    n = x.shape[0]
+    ws = torch.empty(1024 * 8 * 80, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mla_conv1_bwd(_p(x), _p(w), _p(b), _p(d_pooled), n, _p(ws), _p(dw), _p(db), _lib.stream_ptr()))

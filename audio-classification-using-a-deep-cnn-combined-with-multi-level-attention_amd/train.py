@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 from torch.utils.data import Dataset
 
-from . import mla_train, ops
+from . import cnn_train, mla_train, ops
 from .params import *  # noqa: F401,F403
 
 
@@ -51,8 +51,9 @@ def trainable_params(model, feature_extract):
 
 
 class TrainStep:
-    """One fused training step of an ``Ensemble`` (frozen CNN, the reference default
-    ``cnn_trainable=False``; model.py:159-160).
+    """One fused training step of an ``Ensemble``: frozen CNN (the reference default
+    ``cnn_trainable=False``; model.py:159-160) or finetune (every parameter trainable, train.py:96-97;
+    f32 precision).
 
     All trainable parameters are re-seated as views of ONE flat float32 buffer (same for
     gradients and the two Adam moments), so the data-parallel exchange is a single all-reduce
@@ -63,11 +64,12 @@ class TrainStep:
     def __init__(self, clf, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None):
         self.clf, self.lr, self.betas, self.eps, self.t = clf, lr, betas, eps, 0
         self.dist = ops.Dist(process_group)
-        cnn_trainable = [n for n, p in clf.cnn.named_parameters() if p.requires_grad]
-        if cnn_trainable:
-            raise NotImplementedError("finetune (CNN gradients: conv/FC dgrad + wgrad) is not built yet; "
-                                      "trainable CNN parameters: %s ..." % cnn_trainable[:3])
-        named = [(n, p) for n, p in clf.mla.named_parameters() if p.requires_grad and ".fcf." not in n]
+        self.finetune = any(p.requires_grad for p in clf.cnn.parameters())
+        if self.finetune and clf.cnn.precision != "f32":
+            raise NotImplementedError("finetune (CNN gradients) is built for precision='f32' only")
+        if self.finetune and not all(p.requires_grad for p in clf.cnn.parameters()):
+            raise NotImplementedError("partially trainable CNNs are not supported: freeze it or train all of it")
+        named = [(n, p) for n, p in clf.named_parameters() if p.requires_grad and ".fcf." not in n]
         dev = named[0][1].device
         pad4 = lambda k: (k + 3) // 4 * 4                 # every tensor starts 16-byte aligned (GEMM operand rule)
         total = sum(pad4(p.numel()) for _, p in named)
@@ -83,6 +85,7 @@ class TrainStep:
             p.data = self.flat_p[off:off + k].view(p.shape)
             self.grads[n] = self.flat_g[off:off + k].view(p.shape)
             off += pad4(k)
+        self.mla_grads = {n[len("mla."):]: g for n, g in self.grads.items() if n.startswith("mla.")}
 
     def __call__(self, inputs, labels):
         """inputs (B, T, 1, 96, 64) (or whatever ``clf.input`` reshapes), labels (B,) int64.
@@ -91,16 +94,26 @@ class TrainStep:
         clf.train()
         B_global = inputs.shape[0] * self.dist.world
         with torch.no_grad():
-            feats = clf.cnn(clf.input(inputs))
+            x = clf.input(inputs)
+            if self.finetune:
+                feats, cnn_tape = cnn_train.forward(clf.cnn.cnn_model, x)
+            else:
+                feats = clf.cnn(x)
             ctx = mla_train.Ctx(tape=True, dist=self.dist)
             out = mla_train.mla_forward(clf.mla, feats.reshape(-1, T, clf.emb_input_size), ctx)
             loss, dout, hits = ops.cross_entropy(out, labels.to(out.device).long().contiguous(), 1.0 / B_global)
-            mla_train.mla_backward(clf.mla, ctx, dout, self.grads)
+            d_feats = mla_train.mla_backward(clf.mla, ctx, dout, self.mla_grads, need_input_grad=self.finetune)
+            if self.finetune:
+                cnn_train.backward(clf.cnn.cnn_model, cnn_tape, d_feats, self.grads, "cnn.cnn_model.")
             if self.dist.world > 1:
                 self.dist.all_reduce_sum(self.flat_g)
                 self.dist.all_reduce_sum(loss)
             self.t += 1
             ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
+            if self.finetune:                      # derived (repacked / bf16) weight copies are stale now
+                for m in clf.cnn.modules():
+                    if hasattr(m, "_cache"):
+                        m._cache.key = None
         self.last_out = out
         return loss, hits
 
@@ -127,8 +140,11 @@ def train_model(clf, dataloaders, criterion, optimizer, num_epochs=25, patience=
     hyper-parameters are read and the fused HIP step is used instead of autograd."""
     if not isinstance(criterion, nn.CrossEntropyLoss) or not isinstance(optimizer, torch.optim.Adam):
         raise TypeError("the HIP training step implements CrossEntropyLoss + Adam (train.py:369-372)")
-    if finetune or resume:
-        raise NotImplementedError("finetune / resume are outside the built hot path")
+    if resume:
+        raise NotImplementedError("resume from whole-object pickles (train.py:270-272) is outside the built hot path")
+    if finetune:
+        from .model import set_requires_grad
+        set_requires_grad(clf, True)                       # train.py:96-97
     import copy
     g = optimizer.param_groups[0]
     device = next(clf.parameters()).device

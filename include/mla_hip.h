@@ -223,6 +223,32 @@ int mla_axpy(float a, const float* x, float* y, int64_t n, mla_stream_t stream);
 int mla_cross_entropy(const float* x, int64_t ldx, const int64_t* labels, int64_t rows, int K, float inv_total,
                       float* loss, float* dx, int64_t ld_dx, int* n_correct, mla_stream_t stream);
 
+/* --- finetune: gradients of the VGGish feature stack (train.py:96-97, :137), f32, NHWC ------ */
+
+/* Generic 3x3/pad-1 convolution entry over the compiled shape set (VGGish forward with or
+ * without the fused 2x2 pool, and the five dgrad shapes): act != 0 -> bias + ReLU epilogue,
+ * act == 0 -> plain store (transposed convolution; bias may be NULL). f32 only. */
+int mla_conv3x3(const void* in, const void* w_packed, const float* bias, void* out, int64_t n, int H, int W,
+                int cin, int cout, int pool, int act, int dtype, mla_stream_t stream);
+/* (Cout, Cin, 3, 3) -> (Cin, 9, Cout), taps flipped: weights of the dgrad convolution. */
+int mla_conv_repack_dgrad(const float* w_oihw, int64_t cout, int64_t cin, float* out, mla_stream_t stream);
+/* nn.MaxPool2d(2, 2) on a kept NHWC activation (n, H, W, C) -> (n, H/2, W/2, C). */
+int mla_maxpool2x2(const float* a, float* out, int64_t n, int H, int W, int C, mla_stream_t stream);
+/* dZ (n, H, W, C) from the gradient of the layer output: pool != 0: d_out is (n, H/2, W/2, C),
+ * routed to the first maximum of each window of `a` (kept pre-pool, post-ReLU activation) and
+ * masked by ReLU; pool == 0: dZ = d_out * (a > 0). */
+int mla_relu_pool_bwd(const float* a, const float* d_out, float* dz, int64_t n, int H, int W, int C, int pool,
+                      mla_stream_t stream);
+/* dW (Cout, Cin, 3, 3) = sum over pixels of dZ (n,H,W,Cout) x shifted a_in (n,H,W,Cin); f32 MFMA,
+ * deterministic split reduction. workspace: mla_conv_wgrad_workspace_floats() floats. */
+int64_t mla_conv_wgrad_workspace_floats(void);
+int mla_conv_wgrad(const float* dz, const float* a_in, int64_t n, int H, int W, int cin, int cout, float* workspace,
+                   int64_t workspace_floats, float* dw_oihw, mla_stream_t stream);
+/* Backward of features[0..2] (Conv2d(1,64)+ReLU+MaxPool): x (n,96,64), d_pooled (n,48,32,64) ->
+ * dw (64,1,3,3), db (64). workspace: 1024*8*80 floats. */
+int mla_conv1_bwd(const float* x, const float* w, const float* bias, const float* d_pooled, int64_t n, float* workspace,
+                  float* dw, float* db, mla_stream_t stream);
+
 /* torch.optim.Adam step t (train.py:369; no weight decay, no amsgrad) over one flat buffer. */
 int mla_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, int64_t step, mla_stream_t stream);
