@@ -16,8 +16,9 @@
 //                         images, deterministic two-stage reduction that also restores the
 //                         state_dict layout (Cout, Cin, 3, 3).
 //   conv1_bwd             Cin = 1 special case: recomputes the four pre-pool outputs of each pooled
-//                         pixel (bit-identical to the forward), routes the gradient and reduces
-//                         dW (64 x 9) and db (64).
+//                         pixel (f32 fma chain; the forward's MFMA sums differ in the last bits, which
+//                         can only flip the routing between two near-equal maxima), routes the gradient
+//                         and reduces dW (64 x 9) and db (64).
 #include "common.h"
 #include "mma_core.h"
 
@@ -189,7 +190,7 @@ int launch_wgrad(const float* dz, const float* ain, int64_t n, float* partial, i
 
 // ----------------------------------------------------------------------------- conv1 backward ---
 // block (x = pixel block, y = channel group of 8): each lane owns pooled pixels, recomputes the four
-// pre-pool outputs per channel exactly as conv1_kernel does, routes d_pooled and accumulates
+// pre-pool outputs per channel, routes d_pooled to the first maximum and accumulates
 // dW (8 x 9) and db (8) in registers; block tree-reduction -> partial[blockIdx.x][cg][80].
 __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ d_pooled,

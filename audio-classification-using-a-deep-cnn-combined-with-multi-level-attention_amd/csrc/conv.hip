@@ -253,68 +253,122 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
 
 // ---------------------------------------------------------------- conv1 (Cin = 1) ----------
 // x: (N, 96, 64) log-mel examples; w: (64, 1, 3, 3) f32 as stored by the reference; out: pooled
-// NHWC (N, 48, 32, 64). One lane = one pooled pixel x all 64 channels; weights are wave-uniform
-// (scalar loads), the 4x4 input patch lives in registers.
+// NHWC (N, 48, 32, 64). K = 9 taps only, so the layer is bound by the 196 KB/clip (bf16) it writes;
+// the arithmetic still goes to the matrix cores (a VALU version needed 2 304 FMAs per pooled pixel and
+// was VALU-bound at 2.6x the time): bf16 mode pads K to 32 in one v_mfma_f32_16x16x32_bf16 (taps 0..7
+// on the q = 0 lanes, tap 8 on q = 1, zeros elsewhere), f32 mode uses three v_mfma_f32_16x16x4_f32.
+// Workgroup = 8 input rows x 64 columns of one clip; wave w owns rows 2w, 2w+1 = one pooled row; the A
+// operand is gathered from an f32 LDS patch (10 x 66 with halo); pooled + bias + ReLU results are parked
+// in LDS and leave as one contiguous 4 KiB (bf16) block per wave.
+template <typename T> struct Conv1Frag;
+template <> struct Conv1Frag<bf16_t> { u32x4 b[4]; };           // B[k = 8q + e][n = 16 j + r], bf16 pairs
+template <> struct Conv1Frag<float> { float b[3][4]; };         // B[k = 4 s + q][n = 16 j + r]
+
 template <typename TIN, typename T>
-__global__ __launch_bounds__(256) void conv1_kernel(const TIN* __restrict__ x, const float* __restrict__ w,
-                                                    const float* __restrict__ bias, T* __restrict__ out,
-                                                    int64_t n_pix) {
-    // Each wave owns 64 consecutive pooled pixels = one contiguous 64 x 64-channel block of the NHWC
-    // output. Results are parked in LDS ([pixel][64 ch], rows padded by 16 B) and leave as 1 KiB-
-    // contiguous wave stores; storing 16 B per lane at the 128-B pixel stride ran at 1.7 TB/s.
-    constexpr int ROW = 64 * int(sizeof(T)) + 16;              // bytes per pixel row in LDS
-    __shared__ __attribute__((aligned(16))) char stage[4][64 * ROW];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t pix0 = (int64_t(blockIdx.x) * 4 + wave) * 64;
-    const int64_t idx = pix0 + lane;
-    const bool live = idx < n_pix;
-    const int px = int(idx & 31), py = int((idx >> 5) % 48);
-    const int64_t n = idx / (48 * 32);
-    float patch[4][4];
-    _Pragma("unroll") for (int a = 0; a < 4; ++a)
-        _Pragma("unroll") for (int b = 0; b < 4; ++b) {
-            const int iy = 2 * py - 1 + a, ix = 2 * px - 1 + b;
-            patch[a][b] = (live && iy >= 0 && iy < 96 && ix >= 0 && ix < 64) ? load_elem<TIN>(x + (n * 96 + iy) * 64 + ix) : 0.f;
+__global__ __launch_bounds__(256, 4) void conv1_kernel(const TIN* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, T* __restrict__ out, int n_img) {
+    constexpr int PITCH = 68;                                   // floats per patch row (66 used)
+    constexpr int ROW = 64 * int(sizeof(T)) + 16;               // bytes per pooled pixel in the output stage
+    __shared__ float sX[20 * PITCH];                            // second half stays 0.0f: target of the padded taps at any shift
+    __shared__ __attribute__((aligned(16))) char sOut[4 * 32 * ROW];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, q = lane >> 4;
+    const int n_tiles = n_img * 12;                              // 8 input rows of one clip per tile
+
+    // patch of one tile (input rows y0-1 .. y0+8, columns -1 .. 64) -> 3 registers per thread
+    float pre[3];
+    auto patch_load = [&](int tile) {
+        const int img = tile / 12, y0 = (tile % 12) * 8;
+        _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+            const int p = t + 256 * k, yh = p / 66, xh = p % 66;
+            const int gy = y0 + yh - 1, gx = xh - 1;
+            pre[k] = (p < 660 && gy >= 0 && gy < 96 && gx >= 0 && gx < 64) ? load_elem<TIN>(x + (size_t(img) * 96 + gy) * 64 + gx) : 0.f;
         }
-    char* mine = stage[wave] + lane * ROW;
-    for (int cg = 0; cg < 8; ++cg) {
-        float res[8];
-        _Pragma("unroll") for (int c = 0; c < 8; ++c) {
-            const int ch = cg * 8 + c;
-            float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
-            _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)
-                _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {
-                    const float wv = w[ch * 9 + ky * 3 + kx];
-                    a00 = fmaf(patch[ky][kx], wv, a00);
-                    a01 = fmaf(patch[ky][kx + 1], wv, a01);
-                    a10 = fmaf(patch[ky + 1][kx], wv, a10);
-                    a11 = fmaf(patch[ky + 1][kx + 1], wv, a11);
-                }
-            res[c] = fmaxf(fmaxf(fmaxf(a00, a01), fmaxf(a10, a11)) + bias[ch], 0.f);
+    };
+    auto patch_write = [&]() {
+        _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+            const int p = t + 256 * k;
+            if (p < 660) sX[(p / 66) * PITCH + p % 66] = pre[k];
         }
-        if constexpr (sizeof(T) == 2) {
-            u32x4 pk;
-            pk.x = f2bf(res[0]) | (uint32_t(f2bf(res[1])) << 16);
-            pk.y = f2bf(res[2]) | (uint32_t(f2bf(res[3])) << 16);
-            pk.z = f2bf(res[4]) | (uint32_t(f2bf(res[5])) << 16);
-            pk.w = f2bf(res[6]) | (uint32_t(f2bf(res[7])) << 16);
-            *reinterpret_cast<u32x4*>(mine + cg * 16) = pk;
-        } else {
-            *reinterpret_cast<f32x4*>(mine + cg * 32) = f32x4{res[0], res[1], res[2], res[3]};
-            *reinterpret_cast<f32x4*>(mine + cg * 32 + 16) = f32x4{res[4], res[5], res[6], res[7]};
+    };
+    int tile = blockIdx.x;
+    patch_load(tile);
+    for (int p = t; p < 10 * PITCH; p += 256) sX[10 * PITCH + p] = 0.f;
+
+    // per-lane constants: weight fragments and the patch offsets of "its" taps
+    Conv1Frag<T> wf;
+    int toff[8];
+    if constexpr (sizeof(T) == 2) {
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {
+            uint32_t pk[4];
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {
+                const int t0 = 8 * q + 2 * e, t1 = t0 + 1;
+                const float v0 = t0 < 9 ? w[(16 * j + r) * 9 + t0] : 0.f, v1 = t1 < 9 ? w[(16 * j + r) * 9 + t1] : 0.f;
+                pk[e] = f2bf(v0) | (uint32_t(f2bf(v1)) << 16);
+            }
+            wf.b[j] = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        }
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {
+            const int tt = 8 * q + e;
+            toff[e] = tt < 9 ? (tt / 3) * PITCH + tt % 3 + r : 10 * PITCH;      // absolute index (zero slot for padding)
+        }
+    } else {
+        _Pragma("unroll") for (int s3 = 0; s3 < 3; ++s3) {
+            const int tt = 4 * s3 + q;
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) wf.b[s3][j] = tt < 9 ? w[(16 * j + r) * 9 + tt] : 0.f;
+            toff[s3] = tt < 9 ? (tt / 3) * PITCH + tt % 3 + r : 10 * PITCH;
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the block is private to this wave:
-    __builtin_amdgcn_wave_barrier();                            // LDS ops of one wave execute in order
+    float bj[4];
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) bj[j] = bias[16 * j + r];
+
+    // persistent over tiles: weights / offsets load once; the next tile's patch is in flight during the MFMAs
+    char* stage = sOut + wave * 32 * ROW;
+    for (; tile < n_tiles; tile += gridDim.x) {
+    const int img = tile / 12, y0 = (tile % 12) * 8;
+    patch_write();
+    __syncthreads();
+    if (tile + int(gridDim.x) < n_tiles) patch_load(tile + int(gridDim.x));
+    _Pragma("unroll") for (int seg = 0; seg < 4; ++seg) {
+        f32x4 acc[2][4];
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {
+            // tap (ky, kx) of pixel (row, x) sits at sX[(row + ky) * PITCH + x + kx]; padded taps read the zero slot
+            const int shift = (2 * wave + i) * PITCH + 16 * seg;
+            if constexpr (sizeof(T) == 2) {
+                float v[8];
+                _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] = sX[toff[e] + shift];
+                const u32x4 a = u32x4{f2bf(v[0]) | (uint32_t(f2bf(v[1])) << 16), f2bf(v[2]) | (uint32_t(f2bf(v[3])) << 16),
+                                      f2bf(v[4]) | (uint32_t(f2bf(v[5])) << 16), f2bf(v[6]) | (uint32_t(f2bf(v[7])) << 16)};
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) mma_step<bf16_t>(a, wf.b[j], acc[i][j]);
+            } else {
+                _Pragma("unroll") for (int s3 = 0; s3 < 3; ++s3) {
+                    const float a = sX[toff[s3] + shift];
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wf.b[s3][j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        // 2x2 pool (lane-local), bias, ReLU -> LDS stage [pooled x][64 ch]
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {
+            const f32x4 u = acc[0][j], d = acc[1][j];
+            const float p0 = fmaxf(fmaxf(fmaxf(u.x, u.y), fmaxf(d.x, d.y)) + bj[j], 0.f);
+            const float p1 = fmaxf(fmaxf(fmaxf(u.z, u.w), fmaxf(d.z, d.w)) + bj[j], 0.f);
+            const int xo = 8 * seg + 2 * q;
+            store_elem<T>(reinterpret_cast<T*>(stage + xo * ROW) + 16 * j + r, p0);
+            store_elem<T>(reinterpret_cast<T*>(stage + (xo + 1) * ROW) + 16 * j + r, p1);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the stage rows belong to this wave only:
+    __builtin_amdgcn_wave_barrier();                            // LDS operations of one wave execute in order
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    constexpr int PIECES = 64 * int(sizeof(T)) / 16;            // 16-B pieces per pixel: 8 (bf16) or 16 (f32)
-    char* dst = reinterpret_cast<char*>(out + pix0 * 64);
-    const int64_t valid = (n_pix - pix0 < 64 ? n_pix - pix0 : 64) * PIECES;
-    _Pragma("unroll") for (int it = 0; it < PIECES; ++it) {
-        const int piece = it * 64 + lane;                      // linear 16-B piece of the 64-pixel block
-        const int p = piece / PIECES, c = piece % PIECES;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(stage[wave] + p * ROW + c * 16);
-        if (piece < valid) *reinterpret_cast<u32x4*>(dst + size_t(piece) * 16) = v;
+    constexpr int PIECES = 64 * int(sizeof(T)) / 16;            // 16-B pieces per pooled pixel
+    char* dst = reinterpret_cast<char*>(out + ((size_t(img) * 48 + y0 / 2 + wave) * 32) * 64);
+    _Pragma("unroll") for (int it = 0; it < PIECES / 2; ++it) {
+        const int piece = it * 64 + lane, p = piece / PIECES, c = piece % PIECES;
+        *reinterpret_cast<u32x4*>(dst + size_t(piece) * 16) = *reinterpret_cast<const u32x4*>(stage + p * ROW + c * 16);
+    }
+    __syncthreads();                                            // every wave is done with sX before the next patch lands
     }
 }
 
@@ -477,9 +531,11 @@ extern "C" int mla_vggish_conv1(const void* x, int x_dtype, int64_t n, const flo
     MLA_REQUIRE(x && w && bias && out && mla::aligned(out, 16), MLA_E_ARG, "null / misaligned conv1 buffers");
     MLA_REQUIRE((x_dtype == MLA_F32 || x_dtype == MLA_BF16) && (dtype == MLA_F32 || dtype == MLA_BF16), MLA_E_DTYPE,
                 "conv1 dtypes %d -> %d", x_dtype, dtype);
-    const int64_t n_pix = n * 48 * 32;
-    const int64_t blocks = (n_pix + 255) / 256;                 // 4 waves x 64 pooled pixels per workgroup
-    MLA_REQUIRE(blocks <= 0x7fffffff, MLA_E_SHAPE, "batch too large");
+    MLA_REQUIRE(n * 12 <= 0x7fffffff, MLA_E_SHAPE, "batch too large");
+    int dev1 = 0, cus1 = 256;
+    if (hipGetDevice(&dev1) == hipSuccess) hipDeviceGetAttribute(&cus1, hipDeviceAttributeMultiprocessorCount, dev1);
+    const int64_t blocks = n * 12 < int64_t(cus1) * 4 ? n * 12 : int64_t(cus1) * 4;      // persistent: 4 workgroups per CU (VGPR-limited)
+    const int n_pix = int(n);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 g{unsigned(blocks)}, b{256};
     if (x_dtype == MLA_F32 && dtype == MLA_F32)
