@@ -15,16 +15,18 @@ namespace {
 
 using namespace mma;
 
-constexpr int kThreads = 512, kMS = 4, kBM = 128;
+constexpr int kThreads = 512;
 
-template <typename T, typename TO, int NS, bool RELU>
+template <typename T, typename TO, int MS, int NS, bool RELU>
 __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__ A, int64_t lda,
                                                             const T* __restrict__ W, int64_t ldw,
                                                             const float* __restrict__ bias, TO* __restrict__ out,
                                                             int64_t ldo, int M, int N, int K) {
     constexpr int PER = Elem<T>::kPerChunk, KC = Elem<T>::kPerRow;
+    constexpr int kMS = MS, kBM = 2 * MS * 16;                  // 2 (M) x 4 (N) waves: tile (32 MS) x (64 NS)
     constexpr int BN = 4 * NS * 16;
     constexpr int A_BYTES = kBM * kRowBytes, B_BYTES = BN * kRowBytes;
+    constexpr int AP = kBM * 8 / kThreads;                      // 16-byte A pieces per thread and stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
     char* sB = smem + 2 * A_BYTES;
@@ -39,9 +41,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
     _Pragma("unroll") for (int i = 0; i < kMS; ++i)
         _Pragma("unroll") for (int j = 0; j < NS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 areg[2], breg[NS];
+    u32x4 areg[AP], breg[NS];
     auto gload = [&](int s) {
-        _Pragma("unroll") for (int p = 0; p < 2; ++p) {
+        _Pragma("unroll") for (int p = 0; p < AP; ++p) {
             const int piece = t + kThreads * p, row = piece >> 3, ch = piece & 7;
             const int k = s * KC + ch * PER;
             areg[p] = zero16();
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
         }
     };
     auto lwrite = [&](int buf) {
-        _Pragma("unroll") for (int p = 0; p < 2; ++p) {
+        _Pragma("unroll") for (int p = 0; p < AP; ++p) {
             const int piece = t + kThreads * p;
             lds_write16(sA, buf * A_BYTES + tile_off(piece >> 3, piece & 7), areg[p]);
         }
@@ -105,12 +107,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
     }
 }
 
-template <typename T, typename TO, int NS, bool RELU>
+template <typename T, typename TO, int MS, int NS, bool RELU>
 int launch(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* out, int64_t ldo,
            int64_t M, int64_t N, int64_t K, hipStream_t s) {
-    constexpr int BN = 4 * NS * 16;
+    constexpr int kBM = 2 * MS * 16, BN = 4 * NS * 16;
     constexpr int lds = 2 * (kBM + BN) * kRowBytes;
-    auto kern = gemm_kernel<T, TO, NS, RELU>;
+    auto kern = gemm_kernel<T, TO, MS, NS, RELU>;
     MLA_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const dim3 grid{unsigned((M + kBM - 1) / kBM), unsigned((N + BN - 1) / BN)};
     hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, static_cast<const T*>(a), lda, static_cast<const T*>(w), ldw,
@@ -123,10 +125,13 @@ template <typename T, typename TO>
 int dispatch(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* out, int64_t ldo,
              int64_t M, int64_t N, int64_t K, bool relu, hipStream_t s) {
     const bool wide = N > 128 && (N % 256 == 0 || N % 256 > 128);     // 256-wide tiles unless they waste > half a tile
-    if (wide) return relu ? launch<T, TO, 4, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s)
-                          : launch<T, TO, 4, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s);
-    return relu ? launch<T, TO, 2, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s)
-                : launch<T, TO, 2, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s);
+    const bool tall = wide && M >= 4096 && N >= 1024;                  // 256 x 256 tiles once they still fill the chip
+    if (tall) return relu ? launch<T, TO, 8, 4, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s)
+                          : launch<T, TO, 8, 4, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s);
+    if (wide) return relu ? launch<T, TO, 4, 4, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s)
+                          : launch<T, TO, 4, 4, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s);
+    return relu ? launch<T, TO, 4, 2, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s)
+                : launch<T, TO, 4, 2, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s);
 }
 
 }  // namespace
