@@ -21,7 +21,7 @@ template <typename T, typename TO, int MS, int NS, bool RELU>
 __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__ A, int64_t lda,
                                                             const T* __restrict__ W, int64_t ldw,
                                                             const float* __restrict__ bias, TO* __restrict__ out,
-                                                            int64_t ldo, int M, int N, int K) {
+                                                            int64_t ldo, int M, int N, int K, float* __restrict__ partial) {
     constexpr int PER = Elem<T>::kPerChunk, KC = Elem<T>::kPerRow;
     constexpr int kMS = MS, kBM = 2 * MS * 16;                  // 2 (M) x 4 (N) waves: tile (32 MS) x (64 NS)
     constexpr int BN = 4 * NS * 16;
@@ -67,11 +67,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
         }
     };
 
-    const int stages = (K + KC - 1) / KC;
-    gload(0);
-    lwrite(0);
+    // split-K: blockIdx.z owns a contiguous range of K stages and writes raw partial sums
+    const int all_stages = (K + KC - 1) / KC;
+    const int per_split = (all_stages + int(gridDim.z) - 1) / int(gridDim.z);
+    const int s_begin = int(blockIdx.z) * per_split;
+    const int stages = (s_begin + per_split < all_stages ? s_begin + per_split : all_stages);
+    gload(s_begin);
+    lwrite(s_begin & 1);
     __syncthreads();
-    for (int s = 0; s < stages; ++s) {
+    for (int s = s_begin; s < stages; ++s) {
         const int buf = s & 1;
         if (s + 1 < stages) gload(s + 1);
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {
@@ -89,6 +93,21 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
         __syncthreads();
     }
 
+    if (partial) {                          // raw sums of this K range; bias / activation happen in the reduction
+        float* pout = partial + size_t(blockIdx.z) * M * N;
+        _Pragma("unroll") for (int j = 0; j < NS; ++j) {
+            const int n = n0 + (wn * NS + j) * 16 + r;
+            if (n >= N) continue;
+            _Pragma("unroll") for (int i = 0; i < kMS; ++i) {
+                const float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {
+                    const int m = m0 + (wm * kMS + i) * 16 + 4 * q + e;
+                    if (m < M) pout[size_t(m) * N + n] = v[e];
+                }
+            }
+        }
+        return;
+    }
     _Pragma("unroll") for (int j = 0; j < NS; ++j) {
         const int n = n0 + (wn * NS + j) * 16 + r;
         if (n >= N) continue;
@@ -107,17 +126,38 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
     }
 }
 
+// out = act(sum over splits + bias), fixed order
+template <typename TO>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int splits, int64_t M, int N,
+                                                            const float* __restrict__ bias, int relu, TO* __restrict__ out, int64_t ldo) {
+    const int64_t total = M * N;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < total; i += int64_t(gridDim.x) * 256) {
+        const int64_t m = i / N;
+        const int n = int(i - m * N);
+        float v = bias ? bias[n] : 0.f;
+        for (int k = 0; k < splits; ++k) v += partial[size_t(k) * total + i];
+        if (relu) v = fmaxf(v, 0.f);
+        store_elem<TO>(out + m * ldo + n, v);
+    }
+}
+
 template <typename T, typename TO, int MS, int NS, bool RELU>
 int launch(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* out, int64_t ldo,
-           int64_t M, int64_t N, int64_t K, hipStream_t s) {
+           int64_t M, int64_t N, int64_t K, hipStream_t s, int splits = 1, float* partial = nullptr) {
     constexpr int kBM = 2 * MS * 16, BN = 4 * NS * 16;
     constexpr int lds = 2 * (kBM + BN) * kRowBytes;
     auto kern = gemm_kernel<T, TO, MS, NS, RELU>;
     MLA_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    const dim3 grid{unsigned((M + kBM - 1) / kBM), unsigned((N + BN - 1) / BN)};
+    const dim3 grid{unsigned((M + kBM - 1) / kBM), unsigned((N + BN - 1) / BN), unsigned(splits)};
     hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, static_cast<const T*>(a), lda, static_cast<const T*>(w), ldw,
-                       bias, static_cast<TO*>(out), ldo, int(M), int(N), int(K));
+                       bias, static_cast<TO*>(out), ldo, int(M), int(N), int(K), splits > 1 ? partial : nullptr);
     MLA_LAUNCH_OK("gemm_kernel");
+    if (splits > 1) {
+        const int64_t total = M * N;
+        hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3(unsigned((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256),
+                           0, s, partial, splits, M, int(N), bias, int(RELU), static_cast<TO*>(out), ldo);
+        MLA_LAUNCH_OK("splitk_reduce_kernel");
+    }
     return MLA_OK;
 }
 
@@ -135,6 +175,21 @@ int dispatch(const void* a, int64_t lda, const void* w, int64_t ldw, const float
 }
 
 }  // namespace
+
+// Split-K form for reductions over a long K with few output tiles (weight gradients dW = dZ^T . X:
+// M, N = layer widths, K = batch rows): `splits` K ranges accumulate into workspace[splits][M][N]
+// and are summed in fixed order (deterministic). f32 only.
+extern "C" int mla_linear_splitk(const float* a, int64_t lda, const float* w, int64_t ldw, const float* bias, float* out,
+                                 int64_t ldo, int64_t M, int64_t N, int64_t K, int relu, int splits, float* workspace,
+                                 int64_t workspace_floats, mla_stream_t stream) {
+    MLA_REQUIRE(a && w && out && workspace && M > 0 && N > 0 && K > 0 && splits >= 1 && splits <= 64, MLA_E_ARG, "bad split-K GEMM arguments");
+    MLA_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= K && ldw >= K && ldo >= N, MLA_E_SHAPE, "split-K GEMM: 16-byte rows required");
+    MLA_REQUIRE(mla::aligned(a, 16) && mla::aligned(w, 16), MLA_E_ARG, "GEMM operands must be 16-byte aligned");
+    MLA_REQUIRE(workspace_floats >= int64_t(splits) * M * N, MLA_E_ARG, "split-K workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return relu ? launch<float, float, 4, 2, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, splits, workspace)
+                : launch<float, float, 4, 2, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, splits, workspace);
+}
 
 extern "C" int mla_linear(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* out,
                           int64_t ldo, int64_t M, int64_t N, int64_t K, int dtype, int out_dtype, int relu,

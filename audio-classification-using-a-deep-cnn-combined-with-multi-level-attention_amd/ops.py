@@ -14,6 +14,7 @@ BN_EPS = 1e-5
 # Optional per-kernel timing (bench.py): when `profile` is a list, every wrapped call appends
 # (name, start_event, end_event) recorded on the current stream -- the stream the kernels run on.
 profile = None
+_ws = {}                  # per-device scratch buffers (statistics partials, column sums, split-K partials)
 
 
 def _timed(name, fn, *args):
@@ -98,6 +99,17 @@ def linear(a, w, b, relu=False, out_dtype=None, out=None):
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
     else:
         assert out.is_contiguous() and out.numel() == M * N and out.dtype == out_dtype
+    # few output tiles but a long reduction (weight gradients): split K over workgroups
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if a.dtype == torch.float32 and out_dtype == torch.float32 and tiles <= 64 and K >= 2048:
+        splits = int(min(64, max(2, 256 // tiles), K // 512))
+        key = "splitk/" + str(a.device)
+        if key not in _ws or _ws[key].numel() < splits * M * N:
+            _ws[key] = torch.empty(max(splits * M * N, 1 << 22), dtype=torch.float32, device=a.device)
+        ws = _ws[key]
+        _lib.check(_timed("linear_splitk_%dx%d" % (K, N), _lib.lib().mla_linear_splitk, _p(a), a.stride(0), _p(w), w.stride(0), _p(b),
+                          _p(out), N, M, N, K, int(relu), splits, _p(ws), ws.numel(), _lib.stream_ptr()))
+        return out
     _lib.check(_timed("linear_%dx%d" % (K, N), _lib.lib().mla_linear, _p(a), a.stride(0), _p(w), w.stride(0), _p(b), _p(out), N,
                       M, N, K, DT[a.dtype], DT[out_dtype], int(relu), _lib.stream_ptr()))
     return out
@@ -110,9 +122,6 @@ def linear_small(a, w, b):
     out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     _lib.check(_lib.lib().mla_linear_small(_p(a), a.stride(0), _p(w), w.stride(0), _p(b), _p(out), N, M, N, K, _lib.stream_ptr()))
     return out
-
-
-_ws = {}
 
 
 def _workspace(device):

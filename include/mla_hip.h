@@ -131,6 +131,12 @@ int mla_vggish_conv(int layer, const void* in, const void* w_repacked, const flo
 int mla_linear(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* out,
                int64_t ldo, int64_t M, int64_t N, int64_t K, int dtype, int out_dtype, int relu,
                mla_stream_t stream);
+/* mla_linear in f32 with the reduction dimension split over `splits` workgroup ranges (weight
+ * gradients: few output tiles, K = batch rows); partial sums go through workspace
+ * (splits * M * N floats) and are combined in fixed order. */
+int mla_linear_splitk(const float* a, int64_t lda, const float* w, int64_t ldw, const float* bias, float* out,
+                      int64_t ldo, int64_t M, int64_t N, int64_t K, int relu, int splits, float* workspace,
+                      int64_t workspace_floats, mla_stream_t stream);
 /* Same contract in f32 without alignment requirements, for tiny layers (model.py:255 fc). */
 int mla_linear_small(const float* a, int64_t lda, const float* w, int64_t ldw, const float* bias,
                      float* out, int64_t ldo, int64_t M, int64_t N, int64_t K, mla_stream_t stream);

