@@ -35,6 +35,9 @@ FE_BYTES = {torch.float32: 15360 * 4 + 96 * 64 * 4, torch.bfloat16: 15360 * 4 + 
 CONV_DESC = {"conv2": "64->128 @48x32 +pool", "conv3": "128->256 @24x16", "conv4": "256->256 @24x16 +pool",
              "conv5": "256->512 @12x8", "conv6": "512->512 @12x8 +pool"}
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # MI355X_MICROARCH.md: dense bf16 MFMA / f32 MFMA
+# HBM bytes per launch of the dominant kernel at the default batch, from rocprofv3 --pmc FETCH_SIZE (x2, gfx950)
+# + WRITE_SIZE in separate passes: profiles/r01_pmc_traffic.txt. Not measurable from inside this process.
+PMC_TRAFFIC = {("conv4", "bf16", 10240): 3.30e9}
 PEAK_HBM_GBPS = 8000.0
 
 CNN_CONF = dict(cnn_type="vggish", num_classes=10, use_pretrained=False, just_bottlenecks=False,
@@ -171,7 +174,7 @@ def main():
                                    "%s conv+FC" % (args.bags, clips_per_step, args.precision),
                        "bags_per_gpu": args.bags, "clips_per_step_per_gpu": clips_per_step, "parallelism": "dp%d (no collective: independent bags)" % world},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_kernel %s (%s)" % (dom, CONV_DESC[dom]), "achieved": tf, "peak": peak,
-                         "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
+                         "unit": "TFLOP/s", "frac": tf / peak, "traffic": PMC_TRAFFIC.get((dom, args.precision, clips_per_step)),
                          "avg_launch_ms": avg[dom] * 1e3, "flop_per_launch": clips_per_step * CONV_MFLOP[dom] * 1e6},
             "roofline_conv_stack": {"bound": "mfma", "achieved": conv_tf, "peak": peak, "unit": "TFLOP/s", "frac": conv_tf / peak,
                                     "ms": conv_t * 1e3},
