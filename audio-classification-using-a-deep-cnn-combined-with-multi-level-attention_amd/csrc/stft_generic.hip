@@ -88,3 +88,64 @@ extern "C" int mla_mel_log(const float* spectrogram, const float* mel_matrix, in
     MLA_LAUNCH_OK("mel_log_kernel");
     return MLA_OK;
 }
+
+// ---- dataset.create_spec (native path) + split, dataset.py:318-324 and :329-363 -------------------
+// examples: (clips * ex_per_clip, 96, 64) from the front-end; out: (clips, n_frames, 64, frame_len):
+//   out[c][t][band][x] = spec_c[band][t * stride + x],  spec_c[band][col] = ex[c][col / 96][col % 96][band]
+// with the slots >= ex_per_clip of the 4-slot (64, 384) spectrogram zero (0.0, as the reference pads).
+namespace {
+__global__ __launch_bounds__(256) void dataset_frames_kernel(const float* __restrict__ ex, int ex_per_clip, int n_frames,
+                                                             int frame_len, int stride, int64_t total, float* __restrict__ out) {
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < total; i += int64_t(gridDim.x) * 256) {
+        const int x = int(i % frame_len);
+        int64_t r = i / frame_len;
+        const int band = int(r % 64); r /= 64;
+        const int t = int(r % n_frames);
+        const int64_t c = r / n_frames;
+        const int col = t * stride + x, slot = col / 96, fr = col % 96;
+        out[i] = (slot < ex_per_clip && col < 384) ? ex[((c * ex_per_clip + slot) * 96 + fr) * 64 + band] : 0.f;
+    }
+}
+}  // namespace
+
+extern "C" int mla_dataset_frames(const float* examples, int64_t clips, int ex_per_clip, int n_frames, int frame_len,
+                                  int stride, float* out, mla_stream_t stream) {
+    MLA_REQUIRE(out && clips >= 0 && ex_per_clip >= 0 && ex_per_clip <= 4 && n_frames >= 1 && frame_len >= 1 && stride >= 0,
+                MLA_E_ARG, "bad dataset_frames arguments (a clip may hold at most 4 examples, dataset.py:321-322)");
+    MLA_REQUIRE((n_frames - 1) * stride + frame_len <= 384, MLA_E_SHAPE, "frames leave the 384-column spectrogram");
+    MLA_REQUIRE(examples || ex_per_clip == 0, MLA_E_ARG, "null examples");
+    const int64_t total = clips * n_frames * 64 * frame_len;
+    if (total == 0) return MLA_OK;
+    hipLaunchKernelGGL(dataset_frames_kernel, dim3(unsigned((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), examples, ex_per_clip, n_frames, frame_len, stride, total, out);
+    MLA_LAUNCH_OK("dataset_frames_kernel");
+    return MLA_OK;
+}
+
+// ---- vggish.Postprocessor.postprocess, vggish.py:62-102 -------------------------------------------
+// out[n][j] = round((clamp(sum_k E[j][k] (x[n][k] - mu[k]), -2, 2) + 2) * 63.75), round half to even
+namespace {
+__global__ __launch_bounds__(128) void postprocess_kernel(const float* __restrict__ x, const float* __restrict__ ev,
+                                                          const float* __restrict__ mu, int64_t rows, float* __restrict__ out) {
+    __shared__ float xc[128];
+    const int64_t n = blockIdx.x;
+    const int j = threadIdx.x;
+    xc[j] = x[n * 128 + j] - mu[j];
+    __syncthreads();
+    float acc = 0.f;
+    for (int k = 0; k < 128; ++k) acc = fmaf(ev[j * 128 + k], xc[k], acc);
+    acc = fminf(fmaxf(acc, -2.0f), 2.0f);
+    out[n * 128 + j] = rintf((acc + 2.0f) * (255.0f / 4.0f));
+    (void)rows;
+}
+}  // namespace
+
+extern "C" int mla_postprocess(const float* embeddings, const float* pca_eigen_vectors, const float* pca_means, int64_t rows,
+                               float* out, mla_stream_t stream) {
+    MLA_REQUIRE(embeddings && pca_eigen_vectors && pca_means && out && rows >= 0, MLA_E_ARG, "bad postprocess arguments");
+    if (rows == 0) return MLA_OK;
+    hipLaunchKernelGGL(postprocess_kernel, dim3(unsigned(rows)), dim3(128), 0, static_cast<hipStream_t>(stream), embeddings,
+                       pca_eigen_vectors, pca_means, rows, out);
+    MLA_LAUNCH_OK("postprocess_kernel");
+    return MLA_OK;
+}

@@ -186,13 +186,14 @@ class Postprocessor(nn.Module):
     def postprocess(self, embeddings_batch):
         assert len(embeddings_batch.shape) == 2, "Expected 2-d batch, got %r" % (embeddings_batch.shape,)
         assert embeddings_batch.shape[1] == vggish_params.EMBEDDING_SIZE, "Bad batch shape: %r" % (embeddings_batch.shape,)
-        # E (x - mu) = x E^T - E mu: one GEMM with bias -(E mu); the tiny bias product is a GEMM too
-        ev = self.pca_eigen_vectors.detach().contiguous()
-        bias = ops.linear_small(self.pca_means.detach().reshape(1, -1).contiguous(), ev, None).reshape(-1)
-        y = ops.linear(embeddings_batch.detach().float().contiguous(), ev, bias.neg_())
-        y = torch.clamp(y, vggish_params.QUANTIZE_MIN_VAL, vggish_params.QUANTIZE_MAX_VAL)
-        y = torch.round((y - vggish_params.QUANTIZE_MIN_VAL)
-                        * (255.0 / (vggish_params.QUANTIZE_MAX_VAL - vggish_params.QUANTIZE_MIN_VAL)))
+        import ctypes
+        from .. import _lib
+        x = embeddings_batch.detach().float().contiguous()
+        y = torch.empty_like(x)
+        vp = ctypes.c_void_p
+        _lib.check(_lib.lib().mla_postprocess(vp(x.data_ptr()), vp(self.pca_eigen_vectors.detach().contiguous().data_ptr()),
+                                              vp(self.pca_means.detach().contiguous().data_ptr()), x.shape[0], vp(y.data_ptr()),
+                                              _lib.stream_ptr()))
         return torch.squeeze(y)
 
     def forward(self, x):

@@ -94,6 +94,17 @@ int mla_stft_magnitude(const float* signal, int64_t n_samples, const float* wind
 int mla_mel_log(const float* spectrogram, const float* mel_matrix, int64_t frames, int64_t bins, int64_t bands,
                 float log_offset, float* out, mla_stream_t stream);
 
+/* dataset.create_spec (native path, dataset.py:318-324) + split (dataset.py:329-363): the caller of
+ * waveform_to_examples in the reference's data pipeline. examples (clips*ex_per_clip, 96, 64) ->
+ * out (clips, n_frames, 64, frame_len) with out[c][t][band][x] = spec_c[band][t*stride + x], where
+ * spec_c is the (64, 384) concatenation of the clip's <= 4 transposed examples, zero-padded. */
+int mla_dataset_frames(const float* examples, int64_t clips, int ex_per_clip, int n_frames, int frame_len,
+                       int stride, float* out, mla_stream_t stream);
+/* vggish.Postprocessor.postprocess (vggish.py:62-102): PCA, clamp to [-2, 2], 8-bit quantisation
+ * (as float). embeddings (rows, 128), pca_eigen_vectors (128, 128), pca_means (128). */
+int mla_postprocess(const float* embeddings, const float* pca_eigen_vectors, const float* pca_means, int64_t rows,
+                    float* out, mla_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * VGGish feature stack: torchvggish/vggish.py:108-118 (make_layers) applied at :22.
  * Activations are NHWC (N, H, W, C) in the compute dtype (MLA_BF16 or MLA_F32); this

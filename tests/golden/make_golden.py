@@ -296,6 +296,31 @@ def gen_train(ref_model):
     return g
 
 
+def import_reference_dataset():
+    """dataset.py imports librosa / soundfile / h5py at module level; none of them is CALLED by the
+    native (use_librosa=False) spectrogram path, so empty stubs are enough."""
+    for name in ("librosa", "librosa.display", "soundfile", "h5py", "resampy", "torchvision", "torchvision.models"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["librosa"].display = sys.modules["librosa.display"]
+    sys.modules["torchvision.models"].resnet50 = lambda *a, **k: None
+    sys.path.insert(0, REF)
+    import dataset as ref_dataset  # noqa: E402
+    return ref_dataset
+
+
+def gen_dataset():
+    """dataset.create_spec (native VGGish path, dataset.py:318-324) + split (dataset.py:329-363)."""
+    ds = import_reference_dataset()
+    g = {}
+    for name, n in (("clip4s", 64000), ("clip2p5s", 40000), ("clip1s", 16000)):
+        wav = W.uniform(31, W.stream_id("dataset/" + name), n, dtype=np.float64)
+        spec = ds.create_spec(wav, "vggish", 16000, 64000, 96, 64, False, True)
+        g["spec/" + name] = spec.astype(np.float32)
+        g["frames_overlap/" + name] = ds.split(spec, 10, 96, 64, True).astype(np.float32)
+        g["frames_contig/" + name] = ds.split(spec, 10, 96, 64, False).astype(np.float32)
+    return g
+
+
 def save(name, g):
     path = os.path.join(HERE, name)
     np.savez_compressed(path, **g)
@@ -305,7 +330,12 @@ def save(name, g):
 def main():
     torch.set_num_threads(os.cpu_count() or 1)
     mel_features, vggish_input, vggish_mod, ref_model = import_reference()
-    which = set(sys.argv[1:]) or {"frontend", "vggish", "mla", "ensemble", "train"}
+    which = set(sys.argv[1:]) or {"frontend", "vggish", "mla", "ensemble", "train", "dataset"}
+    if "dataset" in which:
+        save("dataset.npz", gen_dataset())
+        which.discard("dataset")
+        if not which:
+            return
     if "frontend" in which:
         save("frontend.npz", gen_frontend(mel_features, vggish_input))
     if "vggish" in which:
