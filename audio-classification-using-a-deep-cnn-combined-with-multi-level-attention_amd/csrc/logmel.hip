@@ -30,9 +30,8 @@ constexpr int kChunk = 32;                                // STFT frames per chu
 constexpr int kThreads = 256;
 constexpr int kSpan = (kChunk - 1) * kHop + kWin;         // 5360 samples per chunk
 constexpr int kXchFloats = 2 * 16 * kXchStride;           // 544 per 16-lane group
-constexpr int kMagStride = 256 + 16;                      // +16 floats: the two frames of a 32-lane half land on different bank halves
-constexpr int kLdsFloats = kSpan + 16 * kXchFloats + 16 * kMagStride + 16 * kBands + kLaneTabFloats;
-constexpr int kLdsBytes = kLdsFloats * 4;                 // 81 600 B -> 2 workgroups per CU
+constexpr int kLdsFloats = kSpan + 16 * kXchFloats + 16 * kBands + kLaneTabFloats;   // magnitudes alias the exchange buffer
+constexpr int kLdsBytes = kLdsFloats * 4;                 // 64 704 B -> 2 workgroups per CU
 static_assert(2 * kLdsBytes <= 160 * 1024, "two workgroups must fit one CU's LDS");
 constexpr int kStageVec = (kSpan / 4 + kThreads - 1) / kThreads;   // 6 float4 per thread
 
@@ -140,13 +139,11 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const InT* __restri
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_pcm = smem;
     float* s_xch = s_pcm + kSpan;
-    float* s_mag = s_xch + 16 * kXchFloats;
-    float* s_row = s_mag + 16 * kMagStride;
+    float* s_row = s_xch + 16 * kXchFloats;
     float* s_tab = s_row + 16 * kBands;      // per-lane mel weights + split twiddles (3.5 KB)
 
     const int t = threadIdx.x, g = t >> 4, j = t & 15;
     float* xg = s_xch + g * kXchFloats;
-    float* mg = s_mag + g * kMagStride;
 
     LaneConsts c;
     load_consts(c, tab, j);
@@ -177,13 +174,20 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const InT* __restri
             group_sync<WAVE>();
             float re[16], im[16];
             phase2_read(j, xg, re, im);
-            group_sync<WAVE>();
-            phase2_write(j, re, im, xg);
-            group_sync<WAVE>();
-            phase3(j, xg, mg, pw);
+            phase2_fft(re, im);
+            // real-FFT split in registers: the mirror bins live in lane (16 - j) & 15 of this group
+            float vr[8], vi[8], pr[8], pi[8];
+            phase3_view(j, re, im, vr, vi);
+            const int partner = (16 - j) & 15;
+            _Pragma("unroll") for (int s = 0; s < 8; ++s) {
+                pr[s] = __shfl(vr[s], partner, 16);
+                pi[s] = __shfl(vi[s], partner, 16);
+            }
+            group_sync<WAVE>();                 // every lane has read its exchange row: the buffer is dead
+            phase3_pairs(j, re, im, pr, pi, xg, pw);        // magnitudes overwrite it
             group_sync<WAVE>();
             float o[4];
-            phase4(c, j, mg, melw, o);
+            phase4(c, j, xg, melw, o);
             _Pragma("unroll") for (int s = 0; s < 4; ++s) s_row[g * kBands + band_of(j, s)] = o[s];
             group_sync<WAVE>();
             // wave w holds rows 4w..4w+3 of this 16-row slab: 256 floats = one float4 per lane,

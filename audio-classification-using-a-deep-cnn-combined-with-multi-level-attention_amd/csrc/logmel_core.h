@@ -16,9 +16,13 @@
 //     phase 2  lane k1 :  Z[k1 + 16 k2] = sum_n2 A_n2[k1] W16^(n2 k2)
 //   2 X[k]     = (Z[k] + conj Z[256-k]) + w^k (Z[k] - conj Z[256-k]) / i,  w = e^(-2 pi i/512)
 //   2 X[256-k] = conj( (Z[k] + conj Z[256-k]) - w^k (...) / i )
-//     phase 3  lane j handles the 8 pairs k = 1 + j + 16 i  -> |2X| for bins 1..255
-//   mel[b] = sum_k (M[k][b] / 2) |2 X[k]| over the band's contiguous bin range (<= 17 bins)
-//     phase 4  lane j owns bands {j, 31-j, 32+j, 63-j} (26..31 non-zeros per lane)
+//     phase 3  stays in registers: lane j holds Z[j + 16 k2]; its mirror bins 256 - (j + 16 s) live in
+//              lane (16 - j) & 15, registers 15 - s, and arrive through ONE 16-lane exchange per value;
+//              lane j then produces |2X| for bins j + 16 s and 256 - j - 16 s, s = 0..7 (lane 0, which
+//              pairs with itself one register off, is fixed up by a register rotation; its s = 0 slot
+//              computes bin 128). Magnitudes go to LDS on top of the dead exchange buffer.
+//   mel[b] = sum_k (M[k][b] / 2) |2 X[k]| over the band's bin range, widened to 16-byte aligned windows
+//     phase 4  lane j owns bands {j, 31-j, 32+j, 63-j}; windows of 8 / 8 / 12 / 20 bins read as float4
 //   out[b] = log(mel[b] + 0.01)
 #ifndef MLA_LOGMEL_CORE_H
 #define MLA_LOGMEL_CORE_H
@@ -34,19 +38,19 @@ namespace logmel {
 constexpr int kWin = 400, kHop = 160, kFft = 512, kBands = 64, kExFrames = 96;
 constexpr int kN1 = 13;                    // non-zero first-stage inputs: 32*n1 + 2*n2 < 400
 constexpr int kXchStride = 17;             // complex elements per exchange row (16 + 1 pad)
-constexpr int kSlot0 = 4, kSlot1 = 6, kSlot2 = 10, kSlot3 = 17;   // padded taps per band slot
-constexpr int kTaps = kSlot0 + kSlot1 + kSlot2 + kSlot3;          // 37
+constexpr int kSlot0 = 8, kSlot1 = 8, kSlot2 = 12, kSlot3 = 20;   // taps per band slot: 4-bin aligned windows
+constexpr int kTaps = kSlot0 + kSlot1 + kSlot2 + kSlot3;          // 48
 
 // table layout (float indices) ------------------------------------------------------
 constexpr int kTabWindow = 0;              // 512 floats: Hann(400) then zeros
 constexpr int kTabTw256 = 512;             // 256 x (cos, -sin)(2 pi m / 256)
 constexpr int kTabTw512 = 1024;            // 129 x (cos, -sin)(2 pi k / 512), padded to 512
 constexpr int kTabMelStart = 1536;         // 16 lanes x 4 slots, int32 first bin of the slot
-constexpr int kMelRow = 44;                // padded per-lane weight row: 44 j mod 64 banks distinct for ds_read_b128
-constexpr int kPwRow = 16;                 // per-lane split twiddles: 8 x (re, im)
+constexpr int kMelRow = 52;                // per-lane weight row pitch: 52 j mod 64 banks distinct for ds_read_b128
+constexpr int kPwRow = 16;                 // per-lane split twiddles: 8 x (re, im) of w^(j + 16 s) (lane 0, s = 0: w^128)
 constexpr int kTabMelW = 1600;             // 16 lanes x kMelRow floats, weights / 2 (zero padded)
-constexpr int kTabPw = kTabMelW + 16 * kMelRow;     // 16 lanes x kPwRow: w^(1 + j + 16 i)
-constexpr int kTabFloats = kTabPw + 16 * kPwRow;    // 2496
+constexpr int kTabPw = kTabMelW + 16 * kMelRow;     // 16 lanes x kPwRow
+constexpr int kTabFloats = kTabPw + 16 * kPwRow;    // 2688
 constexpr int kLaneTabFloats = 16 * (kMelRow + kPwRow);   // contiguous [kTabMelW, kTabFloats): LDS-resident
 
 MLA_HD int band_of(int lane, int slot) {
@@ -167,15 +171,8 @@ MLA_HD void phase2_read(int j, const float* xch, float* re, float* im) {
         im[n2] = xch[2 * (j * kXchStride + n2) + 1];
     }
 }
-// phase 2b: second radix-16, then Z[k1 + 16 k2] -> zbuf[k] (float2), k linear 0..255.
-// (All lanes of the group must have finished phase2_read before any lane writes.)
-MLA_HD void phase2_write(int j, float* re, float* im, float* zbuf) {
-    dft16<false>(re, im);
-    _Pragma("unroll") for (int k2 = 0; k2 < 16; ++k2) {
-        zbuf[2 * (j + 16 * k2)] = re[dr16(k2)];
-        zbuf[2 * (j + 16 * k2) + 1] = im[dr16(k2)];
-    }
-}
+// phase 2b: second radix-16 in place; afterwards Z[j + 16 k2] sits in element dr16(k2) of lane j.
+MLA_HD void phase2_fft(float* re, float* im) { dft16<false>(re, im); }
 
 MLA_HD float fast_sqrt(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -185,31 +182,59 @@ MLA_HD float fast_sqrt(float v) {
 #endif
 }
 
-// phase 3: |2 X[k]| and |2 X[256-k]| for k = 1 + j + 16 i  ->  mag[1..255]
-// pw: this lane's kPwRow split twiddles (table row kTabPw + kPwRow * j).
-MLA_HD void phase3(int j, const float* zbuf, float* mag, const float* pw) {
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {
-        const int k = 1 + j + 16 * i;
-        const float a = zbuf[2 * k], b = zbuf[2 * k + 1];
-        const float p = zbuf[2 * (256 - k)], q = zbuf[2 * (256 - k) + 1];
-        const float er = a + p, ei = b - q;          // 2 E[k]  = Z[k] + conj Z[256-k]
-        float orr = b + q, oi = p - a;                // 2 O[k]  = (Z[k] - conj Z[256-k]) / i
-        cmul(orr, oi, pw[2 * i], pw[2 * i + 1]);        // w^k * 2 O[k]
+// phase 3a: the 8 values lane (16 - j) & 15 needs from this lane: view[s] <-> register 15 - s, i.e.
+// Z[j + 16 (15 - s)]. Lane 0 pairs with itself one register off (256 - 16 s = 16 (16 - s)) and uses its
+// s = 0 slot for bin 128, so it rotates: view[s] = Z[16 (16 - s)] for s >= 1, view[0] = Z[128].
+MLA_HD void phase3_view(int j, const float* re, const float* im, float* vr, float* vi) {
+    _Pragma("unroll") for (int s = 0; s < 8; ++s) {
+        const int gen = dr16(15 - s);                       // register 15 - s
+        const int l0 = dr16(s == 0 ? 8 : 16 - s);           // lane 0: register 16 - s (s = 0: 8)
+        vr[s] = j == 0 ? re[l0] : re[gen];
+        vi[s] = j == 0 ? im[l0] : im[gen];
+    }
+}
+
+// phase 3b: pr/pi = the partner lane's view (exchanged by the caller). |2 X| for bins j + 16 s (mag+)
+// and 256 - j - 16 s (mag-), s = 0..7; lane 0, s = 0: bin 128 from Z[128] alone (written twice).
+// pw: this lane's kPwRow split twiddles.
+MLA_HD void phase3_pairs(int j, const float* re, const float* im, const float* pr, const float* pi, float* mag, const float* pw) {
+    _Pragma("unroll") for (int s = 0; s < 8; ++s) {
+        float a = re[dr16(s)], b = im[dr16(s)];
+        if (s == 0) {                                       // lane 0: Z[128] (register 8) instead of Z[0]
+            a = j == 0 ? re[dr16(8)] : a;
+            b = j == 0 ? im[dr16(8)] : b;
+        }
+        const float p = pr[s], q = pi[s];
+        const float er = a + p, ei = b - q;                 // 2 E[k] = Z[k] + conj Z[256-k]
+        float orr = b + q, oi = p - a;                      // 2 O[k] = (Z[k] - conj Z[256-k]) / i
+        cmul(orr, oi, pw[2 * s], pw[2 * s + 1]);            // w^k * 2 O[k]
         const float ur = er + orr, ui = ei + oi, vr = er - orr, vi = ei - oi;
+        const int k = (s == 0 && j == 0) ? 128 : j + 16 * s;
         mag[k] = fast_sqrt(ur * ur + ui * ui);
         mag[256 - k] = fast_sqrt(vr * vr + vi * vi);
     }
 }
 
-// phase 4: four mel bands per lane, natural log with the reference's 0.01 offset.
-// melw: this lane's kMelRow weights (table row kTabMelW + kMelRow * j).
+// phase 4: four mel bands per lane over 16-byte aligned bin windows (weights zero outside the band),
+// natural log with the reference's 0.01 offset. melw: this lane's kMelRow weights; mag 16-byte aligned.
 MLA_HD void phase4(const LaneConsts& c, int j, const float* mag, const float* melw, float* out4) {
     constexpr int first[4] = {0, kSlot0, kSlot0 + kSlot1, kSlot0 + kSlot1 + kSlot2};
     constexpr int count[4] = {kSlot0, kSlot1, kSlot2, kSlot3};
+    (void)j;
     _Pragma("unroll") for (int s = 0; s < 4; ++s) {
-        const float* m = mag + c.mel_start[s];
+        // 16-byte aligned on both sides (window starts and row offsets are multiples of 4 floats):
+        // explicit vector loads, hipcc cannot prove the alignment of mag + start and falls back to 4-byte reads
+        typedef float v4f __attribute__((vector_size(16)));
+        const v4f* m = reinterpret_cast<const v4f*>(mag + c.mel_start[s]);
+        const v4f* w = reinterpret_cast<const v4f*>(melw + first[s]);
         float acc = 0.f;
-        _Pragma("unroll") for (int t = 0; t < count[s]; ++t) acc += melw[first[s] + t] * m[t];
+        _Pragma("unroll") for (int t = 0; t < count[s] / 4; ++t) {
+            const v4f mv = m[t], wv = w[t];
+            acc += wv[0] * mv[0];
+            acc += wv[1] * mv[1];
+            acc += wv[2] * mv[2];
+            acc += wv[3] * mv[3];
+        }
 #if defined(__HIP_DEVICE_COMPILE__)
         out4[s] = __builtin_amdgcn_logf(acc + 0.01f) * 0.69314718055994530942f;   // v_log_f32 (log2) * ln 2; argument >= 0.01
 #else

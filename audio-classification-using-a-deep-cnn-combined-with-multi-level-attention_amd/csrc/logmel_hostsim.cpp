@@ -23,17 +23,22 @@ extern "C" int64_t hostsim_examples(const float* pcm, int64_t n_samples, float* 
     if (build_tables(tab.data()) != 0) return -1;
     LaneConsts c[16];
     for (int j = 0; j < 16; ++j) load_consts(c[j], tab.data(), j);
-    std::vector<float> xch(2 * 16 * kXchStride), mag(256);
-    float re[16][16], im[16][16];
+    std::vector<float> xch(2 * 16 * kXchStride);
+    float re[16][16], im[16][16], vr[16][8], vi[16][8];
     for (int64_t f = 0; f < examples * kExFrames; ++f) {
         const float* frame = pcm + f * kHop;
         for (int j = 0; j < 16; ++j) phase1(c[j], j, frame, xch.data());
         for (int j = 0; j < 16; ++j) phase2_read(j, xch.data(), re[j], im[j]);
-        for (int j = 0; j < 16; ++j) phase2_write(j, re[j], im[j], xch.data());   // Z aliases xch
-        for (int j = 0; j < 16; ++j) phase3(j, xch.data(), mag.data(), tab.data() + kTabPw + kPwRow * j);
+        for (int j = 0; j < 16; ++j) phase2_fft(re[j], im[j]);
+        for (int j = 0; j < 16; ++j) phase3_view(j, re[j], im[j], vr[j], vi[j]);
+        float* mag = xch.data();                                   // magnitudes alias the dead exchange buffer
+        for (int j = 0; j < 16; ++j) {                             // the 16-lane exchange: partner = (16 - j) & 15
+            const int partner = (16 - j) & 15;
+            phase3_pairs(j, re[j], im[j], vr[partner], vi[partner], mag, tab.data() + kTabPw + kPwRow * j);
+        }
         for (int j = 0; j < 16; ++j) {
             float o[4];
-            phase4(c[j], j, mag.data(), tab.data() + kTabMelW + kMelRow * j, o);
+            phase4(c[j], j, mag, tab.data() + kTabMelW + kMelRow * j, o);
             for (int s = 0; s < 4; ++s) out[f * kBands + band_of(j, s)] = o[s];
         }
     }

@@ -73,11 +73,11 @@ inline int build_tables(float* tab) {
             int k0 = -1, k1 = -1;
             for (int k = 0; k < 257; ++k)
                 if (mel[k * kBands + b] != 0.0) { if (k0 < 0) k0 = k; k1 = k; }
-            if (k0 < 1 || k1 - k0 + 1 > count[s] || k1 > 255) return -1;
+            if (k0 < 1 || k1 > 255) return -1;
             for (int k = k0; k <= k1; ++k)
                 if (mel[k * kBands + b] == 0.0) return -2;          // support must be contiguous
-            int start = k0;
-            if (start + count[s] > 256) start = 256 - count[s];     // keep padded reads inside bins 1..255
+            const int start = k0 / 4 * 4;                           // 16-byte aligned window (float4 reads)
+            if (k1 - start + 1 > count[s] || start + count[s] > 256 || start < 4) return -1;
             starts[4 * lane + s] = start;
             for (int t = 0; t < count[s]; ++t) {
                 const int k = start + t;
@@ -87,7 +87,7 @@ inline int build_tables(float* tab) {
             first += count[s];
         }
         for (int i = 0; i < 8; ++i) {
-            const int k = 1 + lane + 16 * i;
+            const int k = (lane == 0 && i == 0) ? 128 : lane + 16 * i;     // lane 0 uses its s = 0 slot for bin 128
             tab[kTabPw + kPwRow * lane + 2 * i] = tab[kTabTw512 + 2 * k];
             tab[kTabPw + kPwRow * lane + 2 * i + 1] = tab[kTabTw512 + 2 * k + 1];
         }

@@ -68,14 +68,14 @@ def test_tables_match_oracle(L):
     np.testing.assert_allclose(tab[513:1024:2], -np.sin(2 * np.pi * m / 256), atol=1e-7)
     # sparse per-lane mel rows reproduce the dense matrix (weights are stored halved)
     starts = tab[1536:1600].view(np.int32).reshape(16, 4)
-    rows = tab[1600:1600 + 16 * 44].reshape(16, 44)
+    rows = tab[1600:1600 + 16 * 52].reshape(16, 52)
     dense = np.zeros((257, 64))
-    counts = (4, 6, 10, 17)
+    counts = (8, 8, 12, 20)
     for lane in range(16):
         bands = (lane, 31 - lane, 32 + lane, 63 - lane)
         first = 0
         for s in range(4):
-            assert 1 <= starts[lane, s] and starts[lane, s] + counts[s] <= 256
+            assert 4 <= starts[lane, s] and starts[lane, s] % 4 == 0 and starts[lane, s] + counts[s] <= 256
             dense[starts[lane, s]:starts[lane, s] + counts[s], bands[s]] = 2.0 * rows[lane, first:first + counts[s]]
             first += counts[s]
     np.testing.assert_allclose(dense, ref, rtol=1e-7, atol=0)
