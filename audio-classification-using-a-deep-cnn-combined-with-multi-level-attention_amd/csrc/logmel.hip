@@ -26,14 +26,15 @@ namespace {
 
 using namespace logmel;
 
-constexpr int kChunk = 32;                                // STFT frames per chunk (3 per example)
+constexpr int kChunk = 16;                                // STFT frames per chunk (6 per example): one frame per 16-lane group
 constexpr int kThreads = 256;
 constexpr int kSpan = (kChunk - 1) * kHop + kWin;         // 5360 samples per chunk
 constexpr int kXchFloats = 2 * 16 * kXchStride;           // 544 per 16-lane group
-constexpr int kLdsFloats = kSpan + 16 * kXchFloats + 16 * kBands + kLaneTabFloats;   // magnitudes alias the exchange buffer
-constexpr int kLdsBytes = kLdsFloats * 4;                 // 64 704 B -> 2 workgroups per CU
-static_assert(2 * kLdsBytes <= 160 * 1024, "two workgroups must fit one CU's LDS");
-constexpr int kStageVec = (kSpan / 4 + kThreads - 1) / kThreads;   // 6 float4 per thread
+constexpr int kWinFloats = 416;                           // Hann(400) + zeros up to the last index phase 1 touches
+constexpr int kLdsFloats = kSpan + 16 * kXchFloats + kLaneTabFloats + kWinFloats;   // magnitudes and output rows alias the exchange buffer
+constexpr int kLdsBytes = kLdsFloats * 4;                 // 52 032 B -> 3 workgroups per CU
+static_assert(3 * kLdsBytes <= 160 * 1024, "three workgroups must fit one CU's LDS");
+constexpr int kStageVec = (kSpan / 4 + kThreads - 1) / kThreads;   // 3 float4 per thread
 
 static_assert(kSpan % 8 == 0, "chunk span must be vector-loadable");
 static_assert(kExFrames % kChunk == 0, "examples must split into whole chunks");
@@ -56,6 +57,13 @@ __device__ __forceinline__ void group_sync() {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// value held by lane (16 - j) & 15 of the same 16-lane row: DPP row_mirror (j -> 15 - j) followed by
+// row_ror:1 -- two VALU moves, no LDS round trip (verified on hardware: 0 15 14 ... 1)
+__device__ __forceinline__ float from_partner(float v) {
+    const int m = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, m, 0x121, 0xf, 0xf, true));
+}
 
 template <typename InT> struct Stage;
 
@@ -81,7 +89,7 @@ template <> struct Stage<float> {
     }
 };
 
-constexpr int kStageVecI16 = (kSpan / 8 + kThreads - 1) / kThreads;   // 3 x (8 int16) per thread
+constexpr int kStageVecI16 = (kSpan / 8 + kThreads - 1) / kThreads;   // 2 x (8 int16) per thread
 
 template <> struct Stage<int16_t> {
     u32x4 v[kStageVecI16];
@@ -133,14 +141,14 @@ struct ChunkMap {
 };
 
 template <typename InT, typename OutT, bool VEC, bool WAVE>
-__global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const InT* __restrict__ pcm, ChunkMap map,
+__global__ __launch_bounds__(kThreads, 3) void logmel_kernel(const InT* __restrict__ pcm, ChunkMap map,
                                                               int64_t n_chunks, const float* __restrict__ tab,
                                                               OutT* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_pcm = smem;
     float* s_xch = s_pcm + kSpan;
-    float* s_row = s_xch + 16 * kXchFloats;
-    float* s_tab = s_row + 16 * kBands;      // per-lane mel weights + split twiddles (3.5 KB)
+    float* s_tab = s_xch + 16 * kXchFloats;  // per-lane mel weights + split twiddles
+    float* s_win = s_tab + kLaneTabFloats;   // Hann window, read by every group (broadcast)
 
     const int t = threadIdx.x, g = t >> 4, j = t & 15;
     float* xg = s_xch + g * kXchFloats;
@@ -148,6 +156,7 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const InT* __restri
     LaneConsts c;
     load_consts(c, tab, j);
     for (int i = t; i < kLaneTabFloats; i += kThreads) s_tab[i] = tab[kTabMelW + i];
+    for (int i = t; i < kWinFloats; i += kThreads) s_win[i] = tab[kTabWindow + i];
     const float* melw = s_tab + kMelRow * j;
     const float* pw = s_tab + 16 * kMelRow + kPwRow * j;
     // (the first __syncthreads() of the chunk loop orders these writes before any read)
@@ -168,9 +177,8 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const InT* __restri
             map.locate(next, ns, nr);
             stage.template load<VEC>(pcm + ns, t);
         }
-        _Pragma("unroll 1") for (int it = 0; it < kChunk / 16; ++it) {
-            const int f = it * 16 + g;
-            phase1(c, j, s_pcm + f * kHop, xg);
+        {
+            phase1(c, j, s_pcm + g * kHop, s_win, xg);
             group_sync<WAVE>();
             float re[16], im[16];
             phase2_read(j, xg, re, im);
@@ -178,28 +186,28 @@ __global__ __launch_bounds__(kThreads, 2) void logmel_kernel(const InT* __restri
             // real-FFT split in registers: the mirror bins live in lane (16 - j) & 15 of this group
             float vr[8], vi[8], pr[8], pi[8];
             phase3_view(j, re, im, vr, vi);
-            const int partner = (16 - j) & 15;
             _Pragma("unroll") for (int s = 0; s < 8; ++s) {
-                pr[s] = __shfl(vr[s], partner, 16);
-                pi[s] = __shfl(vi[s], partner, 16);
+                pr[s] = from_partner(vr[s]);
+                pi[s] = from_partner(vi[s]);
             }
             group_sync<WAVE>();                 // every lane has read its exchange row: the buffer is dead
-            phase3_pairs(j, re, im, pr, pi, xg, pw);        // magnitudes overwrite it
+            phase3_pairs(j, re, im, pr, pi, xg, pw);        // magnitudes overwrite it (floats 0..255)
             group_sync<WAVE>();
             float o[4];
             phase4(c, j, xg, melw, o);
-            _Pragma("unroll") for (int s = 0; s < 4; ++s) s_row[g * kBands + band_of(j, s)] = o[s];
+            // finished row -> floats 256..319 of the group's (dead) exchange buffer
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) xg[256 + band_of(j, s)] = o[s];
             group_sync<WAVE>();
             // wave w holds rows 4w..4w+3 of this 16-row slab: 256 floats = one float4 per lane,
             // so the store needs no cross-wave barrier and is 1 KiB contiguous per wave.
-            const int64_t o0 = (row0 + it * 16) * kBands;
-            const f32x4 v = reinterpret_cast<const f32x4*>(s_row)[t];
+            const int64_t o0 = row0 * kBands;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(s_xch + (t >> 4) * kXchFloats + 256 + 4 * (t & 15));
             if constexpr (sizeof(OutT) == 4) {
                 reinterpret_cast<f32x4*>(out + o0)[t] = v;
             } else {
                 reinterpret_cast<u32x2*>(out + o0)[t] = u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
             }
-            group_sync<WAVE>();             // s_row / xg / mg are rewritten by the next frame
+            group_sync<WAVE>();                 // the buffer is rewritten by the next frame
         }
         __syncthreads();                    // every frame cut from s_pcm before it is overwritten
     }
@@ -214,7 +222,7 @@ int launch(const void* pcm, int64_t n_wave, int64_t wave_stride, int64_t example
     const bool vec = mla::aligned(pcm, 16) && (wave_stride % vec_elems == 0);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int64_t grid = n_chunks < 2 * int64_t(cus) ? n_chunks : 2 * int64_t(cus);
+    const int64_t grid = n_chunks < 3 * int64_t(cus) ? n_chunks : 3 * int64_t(cus);   // 3 persistent workgroups per CU
     ChunkMap map{wave_stride, int(examples * (kExFrames / kChunk))};
     auto go = [&](auto kern) -> int {
         MLA_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -59,16 +59,11 @@ MLA_HD int band_of(int lane, int slot) {
 
 // per-lane constants, loaded once per workgroup lifetime -------------------------------
 struct LaneConsts {
-    float win_re[kN1], win_im[kN1];        // window at samples 32 n1 + 2 j (+1)
     float tw_re[16], tw_im[16];            // W256^(j k1)
     int mel_start[4];
 };
 
 MLA_HD void load_consts(LaneConsts& c, const float* tab, int j) {
-    _Pragma("unroll") for (int n1 = 0; n1 < kN1; ++n1) {
-        c.win_re[n1] = tab[kTabWindow + 32 * n1 + 2 * j];
-        c.win_im[n1] = tab[kTabWindow + 32 * n1 + 2 * j + 1];
-    }
     _Pragma("unroll") for (int k1 = 0; k1 < 16; ++k1) {
         c.tw_re[k1] = tab[kTabTw256 + 2 * (j * k1)];
         c.tw_im[k1] = tab[kTabTw256 + 2 * (j * k1) + 1];
@@ -138,17 +133,18 @@ MLA_HD void dft16(float* re, float* im) {
 }
 
 // phase 1: lane j = n2. `frame` points at the frame's first sample in the PCM staging
-// buffer (float, 8-byte aligned: frame starts are multiples of 160 samples). Writes
+// buffer (float, 8-byte aligned: frame starts are multiples of 160 samples); `win` is the
+// 400-point periodic Hann (LDS copy on the device, shared by all groups). Writes
 // A[k1] * W256^(j k1) to xch[k1 * 17 + j] (float2 = re, im).
-MLA_HD void phase1(const LaneConsts& c, int j, const float* frame, float* xch) {
+MLA_HD void phase1(const LaneConsts& c, int j, const float* frame, const float* win, float* xch) {
     float re[16], im[16];
     _Pragma("unroll") for (int n1 = 0; n1 < 12; ++n1) {
-        re[n1] = frame[32 * n1 + 2 * j] * c.win_re[n1];
-        im[n1] = frame[32 * n1 + 2 * j + 1] * c.win_im[n1];
+        re[n1] = frame[32 * n1 + 2 * j] * win[32 * n1 + 2 * j];
+        im[n1] = frame[32 * n1 + 2 * j + 1] * win[32 * n1 + 2 * j + 1];
     }
     if (j < 8) {      // samples 384 + 2j (+1) < 400; beyond: zero padding, never read
-        re[12] = frame[384 + 2 * j] * c.win_re[12];
-        im[12] = frame[384 + 2 * j + 1] * c.win_im[12];
+        re[12] = frame[384 + 2 * j] * win[384 + 2 * j];
+        im[12] = frame[384 + 2 * j + 1] * win[384 + 2 * j + 1];
     } else {
         re[12] = 0.f; im[12] = 0.f;
     }

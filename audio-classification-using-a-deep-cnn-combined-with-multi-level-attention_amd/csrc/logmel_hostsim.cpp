@@ -27,7 +27,7 @@ extern "C" int64_t hostsim_examples(const float* pcm, int64_t n_samples, float* 
     float re[16][16], im[16][16], vr[16][8], vi[16][8];
     for (int64_t f = 0; f < examples * kExFrames; ++f) {
         const float* frame = pcm + f * kHop;
-        for (int j = 0; j < 16; ++j) phase1(c[j], j, frame, xch.data());
+        for (int j = 0; j < 16; ++j) phase1(c[j], j, frame, tab.data() + kTabWindow, xch.data());
         for (int j = 0; j < 16; ++j) phase2_read(j, xch.data(), re[j], im[j]);
         for (int j = 0; j < 16; ++j) phase2_fft(re[j], im[j]);
         for (int j = 0; j < 16; ++j) phase3_view(j, re[j], im[j], vr[j], vi[j]);
