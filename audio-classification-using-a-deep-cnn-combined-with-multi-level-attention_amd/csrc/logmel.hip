@@ -1,21 +1,35 @@
 // logmel.hip -- fused log-mel front-end for gfx950: PCM -> 0.96 s VGGish examples in one
 // kernel (reference: vggish_input.py:30-82 -> mel_features.py:192-223).
 //
-// Roofline: HBM. Algorithmic bytes per 0.96 s example: 15 360 new samples x 4 B (f32 PCM;
-// 2 B for int16) + 96 x 64 x 4 B out (2 B for bf16) = 86 016 B; the arithmetic (~1.5 MFLOP
-// per example, f32 VALU) sits at ~17 FLOP/B, just under the f32 ridge, so the kernel is
-// written to keep both the VALU and the memory pipe busy:
+// Roofline: HBM by bytes (algorithmic bytes per 0.96 s example: 15 360 new samples x 4 B for f32
+// PCM, 2 B for int16, + 96 x 64 x 4 B out, 2 B for bf16 = 86 016 B), but what the kernel waits on
+// is its own arithmetic and LDS transposes: ~600 f32 vector instructions per frame and lane
+// (~1.5 MFLOP per example) and two LDS transposes per frame. Measured (rocprofv3 counters,
+// profiles/): the vector pipe and the LDS are each ~50 % busy and the chip drops its clock to
+// 1.9-2.1 GHz under this mix, so the design minimises instructions, LDS cycles and cache traffic
+// per frame rather than chasing occupancy:
 //
-//   - persistent workgroups (256 threads, 2 per CU by LDS) walk 32-frame chunks grid-stride;
-//     per-lane constants (window, twiddles, sparse mel weights: ~110 VGPRs) load once;
-//   - a chunk's PCM span (5 360 samples, frames overlap 2.5x) is read from HBM exactly once,
-//     16 B per lane, coalesced, into registers while the previous chunk computes
-//     (issue-early / write-late staging), then parked in LDS where the 32 frames are cut;
-//   - each 16-lane group owns one STFT frame at a time: radix-16 x radix-16 FFT with one LDS
-//     transpose, real-FFT split, sparse triangular mel (<= 2 bands per bin, 461 non-zeros,
-//     never the dense 257 x 64 product), log -- see logmel_core.h;
-//   - finished rows are staged in LDS and leave as 16 B-per-lane contiguous stores, directly
-//     in (example, 96, 64) layout, so the 0.96 s windowing (vggish_input.py:73-76) is free.
+//   - persistent workgroups (256 threads = 16 groups of 16 lanes, 2 per CU) walk 32-frame
+//     chunks grid-stride; after the table load there is NO workgroup barrier: a 16-lane group
+//     never leaves its wave, so every hand-off is a wave-level fence (compiler ordering only --
+//     a wave's LDS operations execute in issue order);
+//   - each group owns TWO ADJACENT STFT frames per iteration. Its lanes fetch their sample pairs
+//     straight from global memory (128-byte contiguous runs per group and instruction) one
+//     iteration ahead, into registers. Frame B starts 160 = 5 x 32 samples after frame A, so B's
+//     tap n1 is A's tap n1 + 5 under the same window value: 18 loads serve 26 taps. The remaining
+//     frame overlap is served by L2; HBM sees each sample once (rocprofv3 FETCH_SIZE);
+//   - radix-16 x radix-16 FFT with one LDS transpose per frame (rows of 18 complex: 16-byte
+//     aligned and conflict-free for ds_read_b128), real-FFT split in registers via DPP,
+//     magnitudes transposed through the dead exchange buffer, sparse triangular mel (<= 2 bands
+//     per bin, 461 non-zeros, never the dense 257 x 64 product), log -- see logmel_core.h. The
+//     two frames' phases are interleaved so one frame's LDS round trip hides behind the other's
+//     arithmetic, and window / split twiddles / mel weights are read once per pair;
+//   - finished rows are staged in the (dead) exchange buffers and leave as 16 B-per-lane stores,
+//     2 KiB contiguous per wave, directly in (example, 96, 64) layout, so the 0.96 s windowing
+//     (vggish_input.py:73-76) is free.
+//
+// Built with -fno-slp-vectorize (build.py): packed f32 has no throughput advantage on CDNA4 and
+// hipcc pays ~100 v_mov shuffles per frame to form the register pairs.
 #include <hip/hip_bf16.h>
 
 #include "common.h"
@@ -26,18 +40,19 @@ namespace {
 
 using namespace logmel;
 
-constexpr int kChunk = 16;                                // STFT frames per chunk (6 per example): one frame per 16-lane group
+constexpr int kPair = 2;                                  // STFT frames per 16-lane group and iteration (adjacent frames)
+constexpr int kChunk = 16 * kPair;                        // frames per workgroup iteration: a third of an example
 constexpr int kThreads = 256;
-constexpr int kSpan = (kChunk - 1) * kHop + kWin;         // 5360 samples per chunk
-constexpr int kXchFloats = 2 * 16 * kXchStride;           // 544 per 16-lane group
-constexpr int kWinFloats = 416;                           // Hann(400) + zeros up to the last index phase 1 touches
-constexpr int kLdsFloats = kSpan + 16 * kXchFloats + kLaneTabFloats + kWinFloats;   // magnitudes and output rows alias the exchange buffer
-constexpr int kLdsBytes = kLdsFloats * 4;                 // 52 032 B -> 3 workgroups per CU
-static_assert(3 * kLdsBytes <= 160 * 1024, "three workgroups must fit one CU's LDS");
-constexpr int kStageVec = (kSpan / 4 + kThreads - 1) / kThreads;   // 3 float4 per thread
-
-static_assert(kSpan % 8 == 0, "chunk span must be vector-loadable");
+constexpr int kWgPerCu = 2;                                // persistent workgroups per CU (LDS: 2 x 78 KB; 240 VGPRs)
+constexpr int kXchFloats = 2 * 16 * kXchStride;           // 576 per frame in flight
+constexpr int kWinFloats = 416;
+constexpr int kPwPitch = 18;                              // split-twiddle row pitch: 16 rows on distinct bank pairs
+constexpr int kU = 18;                                    // sample pairs per lane for two adjacent frames: 13 + 5
+constexpr int kLdsFloats = kChunk * kXchFloats + 16 * kMelRow + 16 * kPwPitch + kWinFloats;
+constexpr int kLdsBytes = kLdsFloats * 4;
+static_assert(kWgPerCu * kLdsBytes <= 160 * 1024, "the persistent workgroups must fit one CU's LDS");
 static_assert(kExFrames % kChunk == 0, "examples must split into whole chunks");
+static_assert(kHop == 160 && kN1 == 13, "the frame-pair sample sharing assumes hop = 5 * 32 samples");
 
 // group-local synchronisation. A 16-lane group never leaves its wave, and a wave's LDS
 // instructions execute in issue order, so a compiler-level fence is sufficient (WAVE);
@@ -53,163 +68,206 @@ __device__ __forceinline__ void group_sync() {
     }
 }
 
-// clang ext-vectors (not HIP's float4/uint4 structs): those keep staging arrays in scratch
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // value held by lane (16 - j) & 15 of the same 16-lane row: DPP row_mirror (j -> 15 - j) followed by
 // row_ror:1 -- two VALU moves, no LDS round trip (verified on hardware: 0 15 14 ... 1)
 __device__ __forceinline__ float from_partner(float v) {
-    const int m = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true);
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, m, 0x121, 0xf, 0xf, true));
+    const int m = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true);
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(m, 0x121, 0xf, 0xf, true));
 }
 
-template <typename InT> struct Stage;
+// U[m] = (x[32 m + 2 j], x[32 m + 2 j + 1]), m < 18, relative to the first frame of the pair: frame A uses
+// U[0..12], frame B (160 samples later) U[5..17]. U[17] exists for j < 8 only (B's samples 384 .. 399).
+template <typename InT> struct Samples;
 
-template <> struct Stage<float> {
-    f32x4 v[kStageVec];
+template <> struct Samples<float> {
+    f32x2 u[kU];
     template <bool VEC>
-    __device__ __forceinline__ void load(const float* src, int t) {
-        _Pragma("unroll") for (int r = 0; r < kStageVec; ++r) {
-            // clamped, unconditional loads keep the staging registers out of scratch
-            const int q = min(t + kThreads * r, kSpan / 4 - 1);
-            if (VEC) {
-                v[r] = reinterpret_cast<const f32x4*>(src)[q];
-            } else {
-                v[r] = f32x4{src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]};
-            }
+    __device__ __forceinline__ void fetch(const float* frame, int j) {
+        const float* p = frame + 2 * j;
+        _Pragma("unroll") for (int m = 0; m < kU - 1; ++m) {
+            u[m] = VEC ? *reinterpret_cast<const f32x2*>(p + 32 * m) : f32x2{p[32 * m], p[32 * m + 1]};
         }
+        u[kU - 1] = f32x2{0.f, 0.f};
+        if (j < 8) u[kU - 1] = VEC ? *reinterpret_cast<const f32x2*>(p + 32 * (kU - 1)) : f32x2{p[32 * (kU - 1)], p[32 * (kU - 1) + 1]};
     }
-    __device__ __forceinline__ void store(float* s_pcm, int t) const {
-        _Pragma("unroll") for (int r = 0; r < kStageVec; ++r) {
-            const int q = t + kThreads * r;
-            if (q < kSpan / 4) reinterpret_cast<f32x4*>(s_pcm)[q] = v[r];
-        }
-    }
+    __device__ __forceinline__ f32x2 pair(int m) const { return u[m]; }
 };
 
-constexpr int kStageVecI16 = (kSpan / 8 + kThreads - 1) / kThreads;   // 2 x (8 int16) per thread
-
-template <> struct Stage<int16_t> {
-    u32x4 v[kStageVecI16];
+template <> struct Samples<int16_t> {
+    uint32_t u[kU];
     template <bool VEC>
-    __device__ __forceinline__ void load(const int16_t* src, int t) {
-        _Pragma("unroll") for (int r = 0; r < kStageVecI16; ++r) {
-            const int q = min(t + kThreads * r, kSpan / 8 - 1);
-            if (VEC) {
-                v[r] = reinterpret_cast<const u32x4*>(src)[q];
-            } else {
-                const uint16_t* s = reinterpret_cast<const uint16_t*>(src) + 8 * q;
-                v[r] = u32x4{s[0] | (uint32_t(s[1]) << 16), s[2] | (uint32_t(s[3]) << 16),
-                             s[4] | (uint32_t(s[5]) << 16), s[6] | (uint32_t(s[7]) << 16)};
-            }
+    __device__ __forceinline__ void fetch(const int16_t* frame, int j) {
+        const uint16_t* p = reinterpret_cast<const uint16_t*>(frame) + 2 * j;
+        _Pragma("unroll") for (int m = 0; m < kU - 1; ++m) {
+            u[m] = VEC ? *reinterpret_cast<const uint32_t*>(p + 32 * m) : (p[32 * m] | (uint32_t(p[32 * m + 1]) << 16));
         }
+        u[kU - 1] = 0u;
+        if (j < 8) u[kU - 1] = VEC ? *reinterpret_cast<const uint32_t*>(p + 32 * (kU - 1)) : (p[32 * (kU - 1)] | (uint32_t(p[32 * (kU - 1) + 1]) << 16));
     }
     // int16 -> float in [-1, 1): x / 32768 exactly (vggish_input.py:98)
-    __device__ __forceinline__ void store(float* s_pcm, int t) const {
+    __device__ __forceinline__ f32x2 pair(int m) const {
         constexpr float k = 1.0f / 32768.0f;
-        _Pragma("unroll") for (int r = 0; r < kStageVecI16; ++r) {
-            const int q = t + kThreads * r;
-            if (q < kSpan / 8) {
-                f32x4 lo, hi;
-                lo.x = k * float(int16_t(v[r].x & 0xFFFFu)); lo.y = k * float(int16_t(v[r].x >> 16));
-                lo.z = k * float(int16_t(v[r].y & 0xFFFFu)); lo.w = k * float(int16_t(v[r].y >> 16));
-                hi.x = k * float(int16_t(v[r].z & 0xFFFFu)); hi.y = k * float(int16_t(v[r].z >> 16));
-                hi.z = k * float(int16_t(v[r].w & 0xFFFFu)); hi.w = k * float(int16_t(v[r].w >> 16));
-                reinterpret_cast<f32x4*>(s_pcm)[2 * q] = lo;
-                reinterpret_cast<f32x4*>(s_pcm)[2 * q + 1] = hi;
-            }
-        }
+        return f32x2{k * float(int16_t(u[m] & 0xFFFFu)), k * float(int16_t(u[m] >> 16))};
     }
 };
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    const __hip_bfloat16 a = __float2bfloat16(lo), b = __float2bfloat16(hi);
-    return uint32_t(*reinterpret_cast<const uint16_t*>(&a)) | (uint32_t(*reinterpret_cast<const uint16_t*>(&b)) << 16);
-}
-
-// chunk c of the job -> (first PCM sample, first output row)
 struct ChunkMap {
     int64_t wave_stride;
     int chunks_per_wave;           // examples_per_wave * 3
     __device__ __forceinline__ void locate(int64_t c, int64_t& sample0, int64_t& row0) const {
         const int64_t w = c / chunks_per_wave, r = c - w * chunks_per_wave;
         sample0 = w * wave_stride + r * (kChunk * kHop);
-        row0 = c * kChunk;          // rows are (wave, example, frame)-major == chunk-major
+        row0 = c * kChunk;
     }
 };
 
+// the lane's row of the exchange buffer: 16 complex values, 16-byte aligned
+__device__ __forceinline__ void read_row(const float* p, float* re, float* im) {
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(p + 4 * i);
+        re[2 * i] = q.x; im[2 * i] = q.y; re[2 * i + 1] = q.z; im[2 * i + 1] = q.w;
+    }
+}
+
+// phase 3 of one frame: real-FFT split, magnitudes into the (dead) exchange buffer
+template <bool WAVE>
+__device__ __forceinline__ void split_frame(int j, const float* re, const float* im, float* xg, const float* pw) {
+    float vr[8], vi[8], pr[8], pi[8];
+    phase3_view(j, re, im, vr, vi);
+    _Pragma("unroll") for (int s = 0; s < 8; ++s) {
+        pr[s] = from_partner(vr[s]);
+        pi[s] = from_partner(vi[s]);
+    }
+    phase3_pairs(j, re, im, pr, pi, xg, pw);
+}
+
+// phase 4 for both frames of the pair: logmel_core.h's phase4 arithmetic (same summation order per band), each
+// weight vector read once. All 36 LDS reads are issued before the first FMA (the FFT registers are dead here), so
+// the LDS latency is paid once, and the eight accumulators advance in turn (no dependent FMA chains).
+__device__ __forceinline__ void mel_pair(const LaneConsts& c, const float* mag_a, const float* mag_b, const float* melw,
+                                         float* oa, float* ob) {
+    constexpr int first[4] = {0, kSlot0, kSlot0 + kSlot1, kSlot0 + kSlot1 + kSlot2};
+    constexpr int count[4] = {kSlot0 / 4, kSlot1 / 4, kSlot2 / 4, kSlot3 / 4};
+    f32x4 w[kTaps / 4], a[kTaps / 4], b[kTaps / 4];
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {
+        _Pragma("unroll") for (int t = 0; t < count[s]; ++t) {
+            w[first[s] / 4 + t] = *reinterpret_cast<const f32x4*>(melw + first[s] + 4 * t);
+            a[first[s] / 4 + t] = *reinterpret_cast<const f32x4*>(mag_a + c.mel_start[s] + 4 * t);
+            b[first[s] / 4 + t] = *reinterpret_cast<const f32x4*>(mag_b + c.mel_start[s] + 4 * t);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float acc_a[4] = {0.f, 0.f, 0.f, 0.f}, acc_b[4] = {0.f, 0.f, 0.f, 0.f};
+    _Pragma("unroll") for (int t = 0; t < kSlot3 / 4; ++t) {
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) {
+                if (t < count[s]) {
+                    acc_a[s] += w[first[s] / 4 + t][e] * a[first[s] / 4 + t][e];
+                    acc_b[s] += w[first[s] / 4 + t][e] * b[first[s] / 4 + t][e];
+                }
+            }
+        }
+    }
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {
+        oa[s] = __builtin_amdgcn_logf(acc_a[s] + 0.01f) * 0.69314718055994530942f;
+        ob[s] = __builtin_amdgcn_logf(acc_b[s] + 0.01f) * 0.69314718055994530942f;
+    }
+}
+
+template <typename OutT>
+__device__ __forceinline__ void store_piece(OutT* dst, f32x4 v) {
+    if constexpr (sizeof(OutT) == 4) {
+        *reinterpret_cast<f32x4*>(dst) = v;
+    } else {
+        const __hip_bfloat16 b0 = __float2bfloat16(v.x), b1 = __float2bfloat16(v.y), b2 = __float2bfloat16(v.z), b3 = __float2bfloat16(v.w);
+        auto bits = [](const __hip_bfloat16& h) { return uint32_t(*reinterpret_cast<const uint16_t*>(&h)); };
+        *reinterpret_cast<u32x2*>(dst) = u32x2{bits(b0) | (bits(b1) << 16), bits(b2) | (bits(b3) << 16)};
+    }
+}
+
 template <typename InT, typename OutT, bool VEC, bool WAVE>
-__global__ __launch_bounds__(kThreads, 3) void logmel_kernel(const InT* __restrict__ pcm, ChunkMap map,
+__global__ __launch_bounds__(kThreads, kWgPerCu) void logmel_kernel(const InT* __restrict__ pcm, ChunkMap map,
                                                               int64_t n_chunks, const float* __restrict__ tab,
                                                               OutT* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_pcm = smem;
-    float* s_xch = s_pcm + kSpan;
-    float* s_tab = s_xch + 16 * kXchFloats;  // per-lane mel weights + split twiddles
-    float* s_win = s_tab + kLaneTabFloats;   // Hann window, read by every group (broadcast)
+    float* s_xch = smem;
+    float* s_mel = s_xch + kChunk * kXchFloats;   // per-lane mel weights
+    float* s_pw = s_mel + 16 * kMelRow;           // per-lane split twiddles
+    float* s_win = s_pw + 16 * kPwPitch;          // Hann window + zero tail
 
     const int t = threadIdx.x, g = t >> 4, j = t & 15;
-    float* xg = s_xch + g * kXchFloats;
+    float* xa = s_xch + (kPair * g) * kXchFloats;
+    float* xb = xa + kXchFloats;
 
     LaneConsts c;
     load_consts(c, tab, j);
-    for (int i = t; i < kLaneTabFloats; i += kThreads) s_tab[i] = tab[kTabMelW + i];
+    for (int i = t; i < 16 * kMelRow; i += kThreads) s_mel[i] = tab[kTabMelW + i];
+    for (int i = t; i < 16 * kPwRow; i += kThreads) s_pw[(i >> 4) * kPwPitch + (i & 15)] = tab[kTabPw + i];
     for (int i = t; i < kWinFloats; i += kThreads) s_win[i] = tab[kTabWindow + i];
-    const float* melw = s_tab + kMelRow * j;
-    const float* pw = s_tab + 16 * kMelRow + kPwRow * j;
-    // (the first __syncthreads() of the chunk loop orders these writes before any read)
+    const float* melw = s_mel + kMelRow * j;
+    const float* pw = s_pw + kPwPitch * j;
+    __syncthreads();                        // the only workgroup barrier: tables visible
 
-    Stage<InT> stage;
+    Samples<InT> smp;
     int64_t chunk = blockIdx.x, sample0, row0;
     if (chunk < n_chunks) {
         map.locate(chunk, sample0, row0);
-        stage.template load<VEC>(pcm + sample0, t);
+        smp.template fetch<VEC>(pcm + sample0 + (kPair * g) * kHop, j);
     }
     for (; chunk < n_chunks; chunk += gridDim.x) {
         map.locate(chunk, sample0, row0);
-        stage.store(s_pcm, t);
-        __syncthreads();
+        float ra[16], ia[16], rb[16], ib[16];
+        {   // window: frame B's tap n1 is sample pair U[n1 + 5] under the SAME window value as A's tap n1
+            _Pragma("unroll") for (int n1 = 0; n1 < kN1; ++n1) {
+                const f32x2 w = *reinterpret_cast<const f32x2*>(s_win + 32 * n1 + 2 * j);   // zeros beyond 399
+                const f32x2 a = smp.pair(n1), b = smp.pair(n1 + 5);
+                ra[n1] = a.x * w.x; ia[n1] = a.y * w.y;
+                rb[n1] = b.x * w.x; ib[n1] = b.y * w.y;
+            }
+        }
         const int64_t next = chunk + gridDim.x;
-        if (next < n_chunks) {              // in flight while this chunk computes
+        if (next < n_chunks) {              // the next pair's samples fly while this one computes
             int64_t ns, nr;
             map.locate(next, ns, nr);
-            stage.template load<VEC>(pcm + ns, t);
+            smp.template fetch<VEC>(pcm + ns + (kPair * g) * kHop, j);
         }
+        phase1_fft(c, j, ra, ia, xa);
+        group_sync<WAVE>();
+        phase1_fft(c, j, rb, ib, xb);
+        group_sync<WAVE>();
+        // both rows and the split twiddles are requested together; A's second FFT starts when ITS eight reads are back
+        read_row(xa + 2 * (j * kXchStride), ra, ia);
+        read_row(xb + 2 * (j * kXchStride), rb, ib);
+        float pwl[16];
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {
+            const f32x2 q = *reinterpret_cast<const f32x2*>(pw + 2 * i);
+            pwl[2 * i] = q.x; pwl[2 * i + 1] = q.y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        group_sync<WAVE>();                              // every lane has requested its rows: both buffers are dead
+        phase2_fft(ra, ia);
+        split_frame<WAVE>(j, ra, ia, xa, pwl);           // magnitudes of A overwrite its buffer
+        phase2_fft(rb, ib);
+        split_frame<WAVE>(j, rb, ib, xb, pwl);
+        group_sync<WAVE>();
+        float oa[4], ob[4];
+        mel_pair(c, xa, xb, melw, oa, ob);
+        // finished rows -> floats 256..319 of the (dead) buffers, then one 16-byte piece per lane and row:
+        // a wave stores its eight rows as 2 KiB contiguous
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) { xa[256 + band_of(j, s)] = oa[s]; xb[256 + band_of(j, s)] = ob[s]; }
+        group_sync<WAVE>();
         {
-            phase1(c, j, s_pcm + g * kHop, s_win, xg);
-            group_sync<WAVE>();
-            float re[16], im[16];
-            phase2_read(j, xg, re, im);
-            phase2_fft(re, im);
-            // real-FFT split in registers: the mirror bins live in lane (16 - j) & 15 of this group
-            float vr[8], vi[8], pr[8], pi[8];
-            phase3_view(j, re, im, vr, vi);
-            _Pragma("unroll") for (int s = 0; s < 8; ++s) {
-                pr[s] = from_partner(vr[s]);
-                pi[s] = from_partner(vi[s]);
-            }
-            group_sync<WAVE>();                 // every lane has read its exchange row: the buffer is dead
-            phase3_pairs(j, re, im, pr, pi, xg, pw);        // magnitudes overwrite it (floats 0..255)
-            group_sync<WAVE>();
-            float o[4];
-            phase4(c, j, xg, melw, o);
-            // finished row -> floats 256..319 of the group's (dead) exchange buffer
-            _Pragma("unroll") for (int s = 0; s < 4; ++s) xg[256 + band_of(j, s)] = o[s];
-            group_sync<WAVE>();
-            // wave w holds rows 4w..4w+3 of this 16-row slab: 256 floats = one float4 per lane,
-            // so the store needs no cross-wave barrier and is 1 KiB contiguous per wave.
-            const int64_t o0 = row0 * kBands;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(s_xch + (t >> 4) * kXchFloats + 256 + 4 * (t & 15));
-            if constexpr (sizeof(OutT) == 4) {
-                reinterpret_cast<f32x4*>(out + o0)[t] = v;
-            } else {
-                reinterpret_cast<u32x2*>(out + o0)[t] = u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
-            }
-            group_sync<WAVE>();                 // the buffer is rewritten by the next frame
+            const f32x4 va = *reinterpret_cast<const f32x4*>(xa + 256 + 4 * j);
+            const f32x4 vb = *reinterpret_cast<const f32x4*>(xb + 256 + 4 * j);
+            OutT* dst = out + (row0 + kPair * g) * kBands + 4 * j;
+            store_piece<OutT>(dst, va);
+            store_piece<OutT>(dst + kBands, vb);
         }
-        __syncthreads();                    // every frame cut from s_pcm before it is overwritten
+        group_sync<WAVE>();                 // the buffers are rewritten by the next pair
     }
 }
 
@@ -218,11 +276,10 @@ int launch(const void* pcm, int64_t n_wave, int64_t wave_stride, int64_t example
            void* out, bool wave_sync, hipStream_t stream) {
     const int64_t n_chunks = n_wave * examples * (kExFrames / kChunk);
     if (n_chunks == 0) return MLA_OK;
-    constexpr int64_t vec_elems = 16 / sizeof(InT);
-    const bool vec = mla::aligned(pcm, 16) && (wave_stride % vec_elems == 0);
+    const bool vec = mla::aligned(pcm, 2 * sizeof(InT)) && (wave_stride % 2 == 0);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int64_t grid = n_chunks < 3 * int64_t(cus) ? n_chunks : 3 * int64_t(cus);   // 3 persistent workgroups per CU
+    const int64_t grid = n_chunks < kWgPerCu * int64_t(cus) ? n_chunks : kWgPerCu * int64_t(cus);
     ChunkMap map{wave_stride, int(examples * (kExFrames / kChunk))};
     auto go = [&](auto kern) -> int {
         MLA_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -37,7 +37,7 @@ namespace logmel {
 
 constexpr int kWin = 400, kHop = 160, kFft = 512, kBands = 64, kExFrames = 96;
 constexpr int kN1 = 13;                    // non-zero first-stage inputs: 32*n1 + 2*n2 < 400
-constexpr int kXchStride = 17;             // complex elements per exchange row (16 + 1 pad)
+constexpr int kXchStride = 18;             // complex elements per exchange row (16 + 2 pad: rows stay 16-byte aligned and conflict-free for ds_read_b128)
 constexpr int kSlot0 = 8, kSlot1 = 8, kSlot2 = 12, kSlot3 = 20;   // taps per band slot: 4-bin aligned windows
 constexpr int kTaps = kSlot0 + kSlot1 + kSlot2 + kSlot3;          // 48
 
@@ -132,12 +132,11 @@ MLA_HD void dft16(float* re, float* im) {
     dft4(re[12], im[12], re[13], im[13], re[14], im[14], re[15], im[15]);
 }
 
-// phase 1: lane j = n2. `frame` points at the frame's first sample in the PCM staging
-// buffer (float, 8-byte aligned: frame starts are multiples of 160 samples); `win` is the
-// 400-point periodic Hann (LDS copy on the device, shared by all groups). Writes
-// A[k1] * W256^(j k1) to xch[k1 * 17 + j] (float2 = re, im).
-MLA_HD void phase1(const LaneConsts& c, int j, const float* frame, const float* win, float* xch) {
-    float re[16], im[16];
+// phase 1: lane j = n2. phase1_window: windowed samples of the lane, z[16 n1 + j] = (x w)[32 n1 + 2 j] +
+// i (x w)[32 n1 + 2 j + 1]; `frame` points at the frame's first sample, `win` is the 400-point periodic Hann
+// followed by zeros (n1 = 12 reaches index 415). The kernel does the same from registers (samples fetched
+// straight from HBM/L2, one frame ahead).
+MLA_HD void phase1_window(int j, const float* frame, const float* win, float* re, float* im) {
     _Pragma("unroll") for (int n1 = 0; n1 < 12; ++n1) {
         re[n1] = frame[32 * n1 + 2 * j] * win[32 * n1 + 2 * j];
         im[n1] = frame[32 * n1 + 2 * j + 1] * win[32 * n1 + 2 * j + 1];
@@ -148,6 +147,10 @@ MLA_HD void phase1(const LaneConsts& c, int j, const float* frame, const float* 
     } else {
         re[12] = 0.f; im[12] = 0.f;
     }
+}
+// phase1_fft: first radix-16 on re/im[0..12] (13..15 are zero padding), then writes A[k1] * W256^(j k1) to
+// xch[k1 * 17 + j] (float2 = re, im).
+MLA_HD void phase1_fft(const LaneConsts& c, int j, float* re, float* im, float* xch) {
     re[13] = re[14] = re[15] = 0.f;
     im[13] = im[14] = im[15] = 0.f;
     dft16<true>(re, im);
@@ -157,6 +160,11 @@ MLA_HD void phase1(const LaneConsts& c, int j, const float* frame, const float* 
         xch[2 * (k1 * kXchStride + j)] = r;
         xch[2 * (k1 * kXchStride + j) + 1] = i;
     }
+}
+MLA_HD void phase1(const LaneConsts& c, int j, const float* frame, const float* win, float* xch) {
+    float re[16], im[16];
+    phase1_window(j, frame, win, re, im);
+    phase1_fft(c, j, re, im, xch);
 }
 
 // phase 2a: lane j = k1 gathers its row of the exchange buffer (all lanes of the group must
