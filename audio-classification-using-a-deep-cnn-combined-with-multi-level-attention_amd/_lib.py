@@ -9,7 +9,7 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmla_hip.so")
+LIB_PATH = os.environ.get("MLA_HIP_LIB") or os.path.join(HERE, "libmla_hip.so")   # MLA_HIP_LIB: an alternative build (A/B measurements)
 HEADER = os.path.join(os.path.dirname(HERE), "include", "mla_hip.h")
 
 F32, BF16, I16 = 0, 1, 2

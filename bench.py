@@ -95,6 +95,28 @@ def cpu_baseline(ens_sd, gpu_model, device, budget_s=15.0):
     return out
 
 
+def small_batch_leg(ens, rank, device, bags=102, steps=50):
+    """BASELINE config 3 read literally ("batch 1024 clips"): 102 bags = 1 020 clips per step, where one step is
+    ~1.5 ms of GPU work behind ~45 launches. Timed eagerly and as one HIP-graph replay per step."""
+    pcm = synth_pcm(bags, rank, device)
+    out = {"clips_per_step": bags * T_BAG}
+    with torch.no_grad():
+        g = ens.capture_waveforms(pcm)
+        ref = ens.forward_waveforms(pcm).clone()
+        assert torch.equal(g(pcm), ref), "graph replay must reproduce the eager result"
+        for name, fn in (("eager", lambda: ens.forward_waveforms(pcm)), ("hip_graph", lambda: g(pcm))):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            out[name] = {"ms_per_step": dt * 1e3, "clips_per_s": bags * T_BAG / dt}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +125,7 @@ def main():
     ap.add_argument("--bags", type=int, default=1024, help="bags (10 s waveforms) per GPU per step")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-small-batch", action="store_true", help="skip the 1 020-clip eager / HIP-graph leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse N>1 on one GPU)")
     args = ap.parse_args()
 
@@ -183,6 +206,8 @@ def main():
                                   "bytes_per_clip": FE_BYTES[fe_dtype]},
             "kernel_ms": {k: round(v * 1e3, 4) for k, v in sorted(avg.items())},
         }
+        if world == 1 and not args.no_small_batch:
+            result["small_batch"] = small_batch_leg(ens, rank, device)
         if world == 1 and not args.no_cpu_baseline:
             with torch.no_grad():
                 result["cpu_baseline"] = cpu_baseline(sd, ens, device)

@@ -219,3 +219,19 @@ def test_ensemble_wave_to_logits_matches_reference_golden(model, golden, W, jb):
     err = rel_err(out3.cpu(), ref)
     print("bf16 wave->logits rel err vs f32 reference (jb=%d): %.3g" % (jb, err))
     assert err < 5e-2
+
+
+def test_hip_graph_replay_reproduces_eager_forward(model, W):
+    """capture_waveforms: the whole wave -> scores forward as one HIP graph; replays must be bit-identical to the
+    eager path, also for new input data of the captured shape."""
+    ens = load(model.Ensemble("repeat", dict(CNN_CONF, just_bottlenecks=False), [2, 1], torch.device("cuda"), precision="bf16"),
+               W.make_state_dict(6, W.ensemble_shapes((2, 1), False)))
+    ens.eval()
+    pcm = torch.from_numpy(W.waveform(31, 160000, 3)).cuda()
+    with torch.no_grad():
+        g = ens.capture_waveforms(pcm)
+        assert torch.equal(g(pcm), ens.forward_waveforms(pcm))
+        pcm2 = torch.from_numpy(W.waveform(32, 160000, 3)).cuda()
+        assert torch.equal(g(pcm2).clone(), ens.forward_waveforms(pcm2))
+    with pytest.raises(AssertionError):
+        ens.train().capture_waveforms(pcm)
