@@ -51,6 +51,7 @@ def lib():
         L.mla_mel_log.argtypes = [vp, vp, i64, i64, i64, cf, vp, vp]
         L.mla_dataset_frames.argtypes = [vp, i64, ci, ci, ci, ci, vp, vp]
         L.mla_postprocess.argtypes = [vp, vp, vp, i64, vp, vp]
+        L.mla_mono_mix.argtypes = [vp, ci, i64, ci, vp, vp]
         L.mla_conv_repack_weights.argtypes = [vp, i64, i64, vp, ci, vp]
         L.mla_convert_f32.argtypes = [vp, vp, i64, ci, vp]
         L.mla_convert_bf16_to_f32.argtypes = [vp, vp, i64, vp]

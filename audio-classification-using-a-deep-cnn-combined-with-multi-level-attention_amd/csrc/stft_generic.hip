@@ -140,6 +140,34 @@ __global__ __launch_bounds__(128) void postprocess_kernel(const float* __restric
 }
 }  // namespace
 
+template <typename T>
+__global__ __launch_bounds__(256) void mono_mix_kernel(const T* __restrict__ pcm, int64_t n, int channels, double scale,
+                                                        float* __restrict__ out) {
+    const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (i >= n) return;
+    const T* p = pcm + i * channels;
+    double acc = 0.0;                       // numpy's pairwise order is irrelevant: exact for int16, < 1 ulp of f64 for float
+    for (int c = 0; c < channels; ++c) acc += double(p[c]);
+    out[i] = float(acc / double(channels) * scale);
+}
+
+extern "C" int mla_mono_mix(const void* pcm, int pcm_dtype, int64_t n_samples, int channels, float* out, mla_stream_t stream) {
+    MLA_REQUIRE(n_samples >= 0 && channels >= 1, MLA_E_ARG, "bad n_samples %lld / channels %d", (long long)n_samples, channels);
+    MLA_REQUIRE(pcm_dtype == MLA_F32 || pcm_dtype == MLA_I16, MLA_E_DTYPE, "pcm_dtype %d", pcm_dtype);
+    if (n_samples == 0) return MLA_OK;
+    MLA_REQUIRE(pcm && out, MLA_E_ARG, "null pcm/out");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned grid = unsigned((n_samples + 255) / 256);
+    if (pcm_dtype == MLA_F32) {
+        hipLaunchKernelGGL(mono_mix_kernel<float>, dim3(grid), dim3(256), 0, s, static_cast<const float*>(pcm), n_samples, channels, 1.0, out);
+    } else {
+        hipLaunchKernelGGL(mono_mix_kernel<int16_t>, dim3(grid), dim3(256), 0, s, static_cast<const int16_t*>(pcm), n_samples, channels,
+                           1.0 / 32768.0, out);
+    }
+    MLA_LAUNCH_OK("mono_mix_kernel");
+    return MLA_OK;
+}
+
 extern "C" int mla_postprocess(const float* embeddings, const float* pca_eigen_vectors, const float* pca_means, int64_t rows,
                                float* out, mla_stream_t stream) {
     MLA_REQUIRE(embeddings && pca_eigen_vectors && pca_means && out && rows >= 0, MLA_E_ARG, "bad postprocess arguments");

@@ -45,23 +45,27 @@ def _device():
 def as_device_mono(data):
     """ndarray / tensor, 1-D or (samples, channels) -> 1-D device tensor, float32 or int16.
 
-    int16 stays int16 (the kernel scales by 1/32768 itself). Multi-channel input is averaged
-    over axis 1 as vggish_input.py:49-50 does; that mean is the one host-side reduction kept
-    outside the kernel (stereo input is not part of the benchmarked path).
+    Mono int16 stays int16 (the log-mel kernel scales by 1/32768 itself). Multi-channel input is averaged over
+    axis 1 as vggish_input.py:49-50 does, by `mla_mono_mix` on the device (double-precision mean, one rounding).
     """
     dev = _device()
     if isinstance(data, np.ndarray):
-        if data.ndim > 1:
-            data = data.mean(axis=1) if data.dtype != np.int16 else data.astype(np.float64).mean(axis=1) / 32768.0
         if data.dtype != np.int16:
-            data = data.astype(np.float32, copy=False)
-        return torch.from_numpy(np.ascontiguousarray(data)).to(dev)
-    t = data
-    if t.dim() > 1:
-        t = (t.double().mean(dim=1) / (32768.0 if t.dtype == torch.int16 else 1.0)).float()
-    if t.dtype != torch.int16:
-        t = t.float()
-    return t.to(dev).contiguous()
+            data = data.astype(np.float32, copy=False)     # float64 reference input: rounded once, like the mono path
+        t = torch.from_numpy(np.array(data, order="C", copy=True) if not data.flags.writeable else np.ascontiguousarray(data)).to(dev)
+    else:
+        t = data.to(dev)
+        if t.dtype != torch.int16:
+            t = t.float()
+        t = t.contiguous()
+    if t.dim() == 1:
+        return t
+    assert t.dim() == 2, "waveform must be 1-D or (samples, channels)"
+    n, ch = t.shape
+    out = torch.empty((n,), dtype=torch.float32, device=dev)
+    code = _lib.I16 if t.dtype == torch.int16 else _lib.F32
+    _lib.check(_lib.lib().mla_mono_mix(ctypes.c_void_p(t.data_ptr()), code, n, ch, ctypes.c_void_p(out.data_ptr()), _lib.stream_ptr()))
+    return out
 
 
 def waveforms_to_examples(pcm, out_dtype=torch.float32, out=None):

@@ -94,6 +94,10 @@ int mla_stft_magnitude(const float* signal, int64_t n_samples, const float* wind
 int mla_mel_log(const float* spectrogram, const float* mel_matrix, int64_t frames, int64_t bins, int64_t bands,
                 float log_offset, float* out, mla_stream_t stream);
 
+/* Mono mix of waveform_to_examples (vggish_input.py:49-50, `np.mean(data, axis=1)`), with wavfile_to_examples' int16
+ * scaling (vggish_input.py:98) when the input is MLA_I16: interleaved (n_samples, channels) PCM -> (n_samples) float32.
+ * The mean is taken in double precision like numpy's on the reference's float64 data, then rounded once. */
+int mla_mono_mix(const void* pcm, int pcm_dtype, int64_t n_samples, int channels, float* out, mla_stream_t stream);
 /* dataset.create_spec (native path, dataset.py:318-324) + split (dataset.py:329-363): the caller of
  * waveform_to_examples in the reference's data pipeline. examples (clips*ex_per_clip, 96, 64) ->
  * out (clips, n_frames, 64, frame_len) with out[c][t][band][x] = spec_c[band][t*stride + x], where

@@ -74,11 +74,21 @@ def test_batched_unaligned_int16_and_bf16(fe, W):
     view = padded[:, 1:n + 1]
     assert view.data_ptr() % 16 != 0
     assert torch.equal(fe.waveforms_to_examples(view), torch.from_numpy(got).to(dev))
+    # even row stride: the 8-byte vector path (base 8- but not 16-byte aligned) and the scalar path (base 4-byte aligned)
+    for off, vec in ((2, True), (3, False)):
+        wide = torch.zeros((5, n + 9), dtype=torch.float32, device=dev)
+        wide[:, off:n + off] = pcm
+        v2 = wide[:, off:n + off]
+        assert v2.stride(0) % 2 == 0 and (v2.data_ptr() % 8 == 0) == vec and v2.data_ptr() % 16 != 0
+        assert torch.equal(fe.waveforms_to_examples(v2), torch.from_numpy(got).to(dev))
     # int16 PCM: exact 1/32768 scaling in-kernel (vggish_input.py:98)
     i16 = np.round(waves * 20000).astype(np.int16)
     ref16 = ofe.batch_examples(i16 / 32768.0)
     got16 = fe.waveforms_to_examples(torch.from_numpy(i16).to(dev)).cpu().numpy()
     assert np.abs(got16 - ref16).max() <= 1e-4
+    t16 = torch.zeros((5, n + 9), dtype=torch.int16, device=dev)      # int16 rows at an odd element offset: 2-byte aligned only
+    t16[:, 3:n + 3] = torch.from_numpy(i16).to(dev)
+    assert torch.equal(fe.waveforms_to_examples(t16[:, 3:n + 3]).cpu(), torch.from_numpy(got16))
     # bf16 output is the f32 result rounded to nearest-even
     gb = fe.waveforms_to_examples(pcm, out_dtype=torch.bfloat16)
     assert torch.equal(gb.cpu(), torch.from_numpy(got).to(torch.bfloat16))
@@ -152,3 +162,27 @@ def test_standalone_stft_and_logmel_any_configuration(golden, mk, W):
         mf.spectrogram_to_mel_matrix(upper_edge_hertz=5000.0)
     assert mf.frame(torch.arange(10).cuda(), 4, 3).tolist() == [[0, 1, 2, 3], [3, 4, 5, 6], [6, 7, 8, 9]]
     assert np.array_equal(mf.frame(np.arange(10), 4, 3), ofe.frame(np.arange(10), 4, 3))
+
+
+def test_wavfile_to_examples_mono_and_stereo(vi, tmp_path, W):
+    """wavfile_to_examples (vggish_input.py:85-99): 16-bit PCM WAV -> /32768 -> waveform_to_examples; stereo is averaged
+    over channels (vggish_input.py:49-50) by mla_mono_mix on the device. Checked against the oracle on the same samples."""
+    import wave
+    n = 2 * 15360 + 400
+    stereo = np.round(W.waveform(41, n, 2, dtype=np.float64).T * 20000).astype(np.int16)     # (n, 2)
+    for name, data in (("mono", stereo[:, 0]), ("stereo", stereo)):
+        path = str(tmp_path / (name + ".wav"))
+        with wave.open(path, "wb") as wf:
+            wf.setnchannels(1 if data.ndim == 1 else 2)
+            wf.setsampwidth(2)
+            wf.setframerate(16000)
+            wf.writeframes(np.ascontiguousarray(data).tobytes())
+        got = vi.wavfile_to_examples(path, return_tensor=False)
+        samples = data / 32768.0
+        ref = ofe.waveform_to_examples(samples if samples.ndim == 1 else samples.mean(axis=1))
+        assert got.shape == ref.shape == (2, 96, 64)
+        assert np.abs(got - ref).max() <= 1e-4, name
+    # float stereo through waveform_to_examples directly
+    fl = W.waveform(42, n, 2, dtype=np.float64).T
+    got = vi.waveform_to_examples(fl, 16000, return_tensor=False)
+    assert np.abs(got - ofe.waveform_to_examples(fl.mean(axis=1))).max() <= 1e-4
