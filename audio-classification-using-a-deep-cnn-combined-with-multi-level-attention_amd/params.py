@@ -1,7 +1,8 @@
 """Model constants consumed by the hot path.
 
 Mirrors the model section of the reference's ``params.py:24-32`` (``T, M_VGGISH,
-M_VGGISH_JB, H, DR, K, S_VGGISH_SHAPE``). The dataset paths, class names and the
+M_VGGISH_JB, H, DR, K, S_VGGISH_SHAPE``) and the class labels (``params.py:15-16``: UrbanSound8K's ten
+classes in classID order, used by ``train.test_model``'s report). The dataset paths and the
 ResNet constants of the reference are outside SURVEY.md section 8 and are not
 reproduced. ``model.py`` binds these at import time exactly as the reference's
 ``from params import *`` does (``model.py:9``), so they are compile-time
@@ -15,6 +16,8 @@ M_VGGISH_JB = 512 * 6 * 4     # flattened conv bottleneck width (just_bottleneck
 H = 600                       # hidden width of the embedded mappings
 DR = 0.4                      # dropout rate inside the embedded mappings
 K = 10                        # classes
+TARGET_NAMES = ["air_conditioner", "car_horn", "children_playing", "dog_bark", "drilling", "engine_idling", "gun_shot",
+                "jackhammer", "siren", "street_music"]
 
 BATCH_SIZE = 8
 NUM_EPOCHS = 25

@@ -1,8 +1,9 @@
 """Drop-in for the hot-path part of the reference's ``train.py``: the inner training step
 (train.py:119-142), ``trainable_params`` (train.py:283-303), the Adam / CrossEntropyLoss choice
-(train.py:369-372) and ``H5Loader`` (train.py:31-48), plus a compact ``train_model`` epoch loop
-with the reference's signature. Plotting, sklearn reports and whole-object pickled checkpoints
-(train.py:182-281) are host orchestration outside SURVEY.md section 8 and are not reproduced.
+(train.py:369-372), ``H5Loader`` (train.py:31-48) and the shell around them: the
+``train_model`` epoch loop with early stopping, best-weights restore, checkpoint / resume, ``test_model`` with the
+classification summary, ``save_model`` / ``load_model``. Checkpoints hold tensors and numbers only (the reference
+pickles whole objects, train.py:249-262); the confusion-matrix plot is not reproduced.
 
 ``TrainStep`` fuses zero_grad -> forward -> CrossEntropyLoss -> backward -> Adam into HIP kernel
 calls; under ``torch.distributed`` it shards nothing itself (each rank feeds its own bags) and
@@ -10,8 +11,10 @@ exchanges (a) BatchNorm statistics (SyncBN, so the result equals the reference's
 step on the global batch) and (b) ONE flat gradient buffer with an RCCL all-reduce over xGMI.
 """
 
+import os
 import time
 
+import numpy as np
 import torch
 import torch.nn as nn
 from torch.utils.data import Dataset
@@ -87,6 +90,18 @@ class TrainStep:
             off += pad4(k)
         self.mla_grads = {n[len("mla."):]: g for n, g in self.grads.items() if n.startswith("mla.")}
 
+    def state_dict(self):
+        """Optimizer state as plain tensors (Adam moments over the flat buffer + step count): what
+        ``optimizer.state_dict()`` holds in the reference's checkpoints (train.py:249-258)."""
+        return {"adam_m": self.flat_m.clone(), "adam_v": self.flat_v.clone(), "step": torch.tensor(self.t),
+                "lr": torch.tensor(self.lr), "betas": torch.tensor(self.betas), "eps": torch.tensor(self.eps)}
+
+    def load_state_dict(self, sd):
+        assert sd["adam_m"].numel() == self.flat_m.numel(), "checkpoint was written for a different set of trainable parameters"
+        self.flat_m.copy_(sd["adam_m"]); self.flat_v.copy_(sd["adam_v"]); self.t = int(sd["step"])
+        self.lr, self.eps = float(sd["lr"]), float(sd["eps"])
+        self.betas = tuple(float(b) for b in sd["betas"])
+
     def __call__(self, inputs, labels):
         """inputs (B, T, 1, 96, 64) (or whatever ``clf.input`` reshapes), labels (B,) int64.
         Returns (loss, n_correct) as device tensors (no host sync; train.py:141-142 syncs via .item())."""
@@ -118,9 +133,9 @@ class TrainStep:
         return loss, hits
 
 
-def _evaluate(clf, loader, device):
+def _evaluate(clf, loader, device, collect=False):
     clf.eval()
-    tot_loss, tot_hits, n = 0.0, 0, 0
+    tot_loss, tot_hits, n, preds, trues = 0.0, 0, 0, [], []
     with torch.no_grad():
         for inputs, labels in loader:
             inputs, labels = inputs.to(device).float(), labels.to(device).long()
@@ -129,7 +144,80 @@ def _evaluate(clf, loader, device):
             tot_loss += float(loss) * inputs.shape[0]
             tot_hits += int(hits)
             n += inputs.shape[0]
+            if collect:
+                preds.append(torch.max(out, 1)[1].cpu()); trues.append(labels.cpu())
+    if collect:
+        return tot_loss / max(n, 1), tot_hits / max(n, 1), torch.cat(preds), torch.cat(trues)
     return tot_loss / max(n, 1), tot_hits / max(n, 1)
+
+
+def classification_summary(y_true, y_pred, target_names=TARGET_NAMES):
+    """Per-class precision / recall / f1 / support + accuracy and macro / weighted averages, laid out like
+    sklearn's ``classification_report(output_dict=True)`` (train.py:246), and the row-normalised confusion
+    matrix in percent (train.py:237-241). Plain numpy: nothing here is on the GPU path."""
+    y_true, y_pred = np.asarray(y_true), np.asarray(y_pred)
+    k = len(target_names)
+    cm = np.zeros((k, k), dtype=np.float64)
+    np.add.at(cm, (y_true, y_pred), 1.0)
+    tp, support, predicted = np.diag(cm), cm.sum(axis=1), cm.sum(axis=0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        prec = np.where(predicted > 0, tp / predicted, 0.0)
+        rec = np.where(support > 0, tp / support, 0.0)
+        f1 = np.where(prec + rec > 0, 2 * prec * rec / (prec + rec), 0.0)
+        cm_pct = np.where(support[:, None] > 0, cm * 100.0 / support[:, None], 0.0).astype(np.float32)
+    res = {name: {"precision": float(prec[i]), "recall": float(rec[i]), "f1-score": float(f1[i]), "support": int(support[i])}
+           for i, name in enumerate(target_names)}
+    total = float(support.sum())
+    res["accuracy"] = float(tp.sum() / total) if total else 0.0
+    for tag, wts in (("macro avg", np.ones(k)), ("weighted avg", support)):
+        w = wts / wts.sum() if wts.sum() else wts
+        res[tag] = {"precision": float((prec * w).sum()), "recall": float((rec * w).sum()), "f1-score": float((f1 * w).sum()),
+                    "support": int(total)}
+    return res, cm_pct
+
+
+def test_model(model, dataloader, criterion=None, optimizer=None):
+    """train.py:182-247: final test pass -> (test accuracy, classification summary dict). The confusion-matrix
+    plot of the reference is not reproduced; the matrix itself is returned under ``results["confusion_matrix_pct"]``."""
+    if dataloader is None:
+        return None
+    device = next(model.parameters()).device
+    since = time.time()
+    print("Testing"); print("-" * 10)
+    loss, acc, preds, trues = _evaluate(model, dataloader, device, collect=True)
+    print("{} Loss: {:.4f}, Acc: {:.4f}".format("test", loss, acc))
+    print("Testing complete in {:.0f}s".format(time.time() - since))
+    results, cm = classification_summary(trues.numpy(), preds.numpy())
+    results["confusion_matrix_pct"] = cm
+    return acc, results
+
+
+def _save_checkpoint(model, step, epoch, loss, accuracy, history, path):
+    """train.py:249-258 with tensors and numbers only (the reference pickles whole objects; these files load with
+    ``torch.load(weights_only=True)``): model ``state_dict`` + Adam state of the fused step + bookkeeping."""
+    torch.save({"epoch": int(epoch), "model": model.state_dict(), "optimizer": step.state_dict(), "loss": float(loss),
+                "accuracy": float(accuracy), "history": [float(h) for h in history]}, path)
+
+
+def _resume_from_checkpoint(path, model, step):
+    """train.py:260-262: restores `model` and `step` in place, returns (epoch, loss, accuracy, history)."""
+    d = torch.load(path, map_location=next(model.parameters()).device, weights_only=True)
+    model.load_state_dict(d["model"])
+    step.load_state_dict(d["optimizer"])
+    return d["epoch"], d["loss"], d["accuracy"], list(d["history"])
+
+
+def save_model(model, path):
+    """train.py:265-266."""
+    torch.save(model.state_dict(), path)
+
+
+def load_model(model_args, path):
+    """train.py:268-271: build an Ensemble from its constructor arguments and load a ``save_model`` file."""
+    from .model import Ensemble
+    m = Ensemble(**model_args)
+    m.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+    return m
 
 
 def train_model(clf, dataloaders, criterion, optimizer, num_epochs=25, patience=10, save_model_path=None, resume=False,
@@ -137,11 +225,11 @@ def train_model(clf, dataloaders, criterion, optimizer, num_epochs=25, patience=
     """Epoch loop with the reference's signature and return value (train.py:53-179):
     (model with the best-validation weights, validation accuracy history, test accuracy).
     ``criterion`` must be nn.CrossEntropyLoss and ``optimizer`` torch.optim.Adam: their
-    hyper-parameters are read and the fused HIP step is used instead of autograd."""
+    hyper-parameters are read and the fused HIP step is used instead of autograd. Checkpoints hold tensors only
+    (``_save_checkpoint``); ``resume=True`` continues from ``save_model_path`` (epoch, best accuracy, history,
+    weights and Adam moments), as train.py:80-94 does from its pickled objects."""
     if not isinstance(criterion, nn.CrossEntropyLoss) or not isinstance(optimizer, torch.optim.Adam):
         raise TypeError("the HIP training step implements CrossEntropyLoss + Adam (train.py:369-372)")
-    if resume:
-        raise NotImplementedError("resume from whole-object pickles (train.py:270-272) is outside the built hot path")
     if finetune:
         from .model import set_requires_grad
         set_requires_grad(clf, True)                       # train.py:96-97
@@ -149,10 +237,16 @@ def train_model(clf, dataloaders, criterion, optimizer, num_epochs=25, patience=
     g = optimizer.param_groups[0]
     device = next(clf.parameters()).device
     step = TrainStep(clf, lr=g["lr"], betas=g["betas"], eps=g["eps"])
-    since, val_acc_history, best_acc, best_epoch = time.time(), [], 0.0, 0
+    since, val_acc_history, best_acc, best_epoch, first_epoch = time.time(), [], 0.0, 0, 0
+    if resume:
+        assert save_model_path is not None
+        if not os.path.exists(save_model_path):
+            raise Exception("No such model file in the specified path.")
+        ep, _, best_acc, val_acc_history = _resume_from_checkpoint(save_model_path, clf, step)
+        first_epoch, best_epoch = ep + 1, ep
     best_wts = copy.deepcopy(clf.state_dict())
     test_loader = dataloaders.pop("test", None)
-    for epoch in range(num_epochs):
+    for epoch in range(first_epoch, num_epochs):
         print("Epoch {}/{}".format(epoch + 1, num_epochs)); print("-" * 10)
         run_loss, run_hits, n = 0.0, 0, 0
         for inputs, labels in dataloaders["train"]:
@@ -165,10 +259,14 @@ def train_model(clf, dataloaders, criterion, optimizer, num_epochs=25, patience=
         if v_acc > best_acc:
             best_acc, best_epoch, best_wts = v_acc, epoch, copy.deepcopy(clf.state_dict())
             if save_model_path:
-                torch.save(clf.state_dict(), save_model_path)
+                _save_checkpoint(clf, step, epoch, v_loss, best_acc, val_acc_history, save_model_path)
+                print("Model checkpoint saved successfully in the given path!")
         if patience is not None and epoch - best_epoch >= patience:
             break
     print("Training complete in {:.0f}s; best val Acc: {:4f}".format(time.time() - since, best_acc))
     clf.load_state_dict(best_wts)
-    test_acc = _evaluate(clf, test_loader, device)[1] if test_loader is not None else None
-    return clf, val_acc_history, test_acc
+    tested = test_model(clf, test_loader)
+    final = save_model_path or "best_weights.h5"
+    root, ext = os.path.splitext(final)
+    save_model(clf, root + ("_final_finetuned" if finetune else "_final") + ext)       # train.py:173-177
+    return clf, val_acc_history, (tested[0] if tested is not None else None)

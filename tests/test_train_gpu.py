@@ -149,3 +149,51 @@ def test_finetune_curve_matches_reference_golden(golden, mk, W):
     ens.eval()
     ev = ens(mk.synth_bags(999, 4)[0].cuda())
     np.testing.assert_allclose(ev.cpu().numpy(), g["finetune/eval_after"], rtol=0, atol=2e-2)
+
+
+def test_train_model_checkpoint_resume_and_report(tmp_path, mk, W):
+    """The shell around the step (train.py:53-179, :182-262): epoch loop, checkpoint at each validation improvement,
+    resume (weights + Adam moments + epoch + history) == uninterrupted run, bit for bit; test_model's summary agrees
+    with sklearn's classification_report."""
+    from torch.utils.data import DataLoader, TensorDataset
+    T = importlib.import_module(PKG + ".train")
+
+    def loaders():
+        x, y = mk.synth_bags(5, 16)
+        ds = TensorDataset(torch.as_tensor(x), torch.as_tensor(y))
+        return {"train": DataLoader(ds, batch_size=8), "val": DataLoader(ds, batch_size=8), "test": DataLoader(ds, batch_size=8)}
+
+    def run(epochs, path, resume, ens=None):
+        ens = ens or build(mk, W)
+        for m in ens.modules():                       # dropout off: this test is about bookkeeping, masks are covered above
+            if hasattr(m, "p") and m.__class__.__name__ == "Dropout":
+                m.p = 0.0
+        opt = torch.optim.Adam(T.trainable_params(ens, True), lr=1e-3)
+        return T.train_model(ens, loaders(), torch.nn.CrossEntropyLoss(), opt, num_epochs=epochs, patience=None,
+                             save_model_path=path, resume=resume)
+
+    full, hist_full, acc_full = run(3, str(tmp_path / "full.pt"), False)
+    part, hist_part, _ = run(2, str(tmp_path / "part.pt"), False)
+    ck = torch.load(str(tmp_path / "part.pt"), weights_only=True)            # tensors and numbers only
+    assert set(ck) == {"epoch", "model", "optimizer", "loss", "accuracy", "history"}
+    if ck["epoch"] == 1:                                                     # the last epoch improved: resume continues from it
+        resumed, hist_res, acc_res = run(3, str(tmp_path / "part.pt"), True)
+        assert hist_res[:2] == hist_part
+        if hist_full[2] > max(hist_full[:2]):                                # epoch 3 is the best of both runs -> same final weights
+            for (k, a), (_, b) in zip(full.state_dict().items(), resumed.state_dict().items()):
+                assert torch.equal(a, b), k
+            assert acc_res == acc_full
+    assert os.path.exists(str(tmp_path / "full_final.pt"))
+    loaded = T.load_model(dict(input_conf="repeat", cnn_conf=dict(mk.CNN_CONF), model_conf=[2, 1], device=torch.device("cuda")),
+                          str(tmp_path / "full_final.pt")).cuda()
+    acc, results = T.test_model(loaded, loaders()["test"])
+    assert acc == acc_full
+    # summary vs sklearn on the same predictions
+    from sklearn.metrics import classification_report
+    _, _, preds, trues = T._evaluate(loaded, loaders()["test"], torch.device("cuda"), collect=True)
+    ref = classification_report(trues, preds, labels=list(range(10)), target_names=T.TARGET_NAMES, output_dict=True, zero_division=0)
+    for name in T.TARGET_NAMES + ["macro avg", "weighted avg"]:
+        for key in ("precision", "recall", "f1-score"):
+            want = ref[name][key]
+            assert abs(results[name][key] - want) < 1e-9, (name, key)
+    assert abs(results["accuracy"] - acc) < 1e-12
