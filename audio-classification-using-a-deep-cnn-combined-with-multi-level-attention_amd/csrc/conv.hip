@@ -57,6 +57,25 @@ struct Cfg {
     static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
 };
 
+// N consecutive output channels of one pixel as ONE store (N = 2 or 4; p is N * sizeof(T) aligned)
+template <typename T, int N> __device__ __forceinline__ void store_vec(T* p, const float* v);
+template <> __device__ __forceinline__ void store_vec<float, 4>(float* p, const float* v) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+}
+template <> __device__ __forceinline__ void store_vec<float, 2>(float* p, const float* v) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<f32x2*>(p) = f32x2{v[0], v[1]};
+}
+template <> __device__ __forceinline__ void store_vec<bf16_t, 4>(bf16_t* p, const float* v) {
+    *reinterpret_cast<u32x2*>(p) = u32x2{uint32_t(f2bf(v[0])) | (uint32_t(f2bf(v[1])) << 16), uint32_t(f2bf(v[2])) | (uint32_t(f2bf(v[3])) << 16)};
+}
+template <> __device__ __forceinline__ void store_vec<bf16_t, 2>(bf16_t* p, const float* v) {
+    *reinterpret_cast<uint32_t*>(p) = uint32_t(f2bf(v[0])) | (uint32_t(f2bf(v[1])) << 16);
+}
+
+template <> __device__ __forceinline__ void store_vec<float, 1>(float* p, const float* v) { *p = v[0]; }
+template <> __device__ __forceinline__ void store_vec<bf16_t, 1>(bf16_t* p, const float* v) { p->bits = f2bf(v[0]); }
+
 template <typename C>
 __device__ __forceinline__ int a_swizzle(int xh, int img) {
     // bits 1-2 only (see mma_core.h); for W = 8 the two images of a subtile occupy complementary
@@ -146,7 +165,11 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
     u32x4 breg[C::NS];
     auto b_load = [&](int c0, int tap) {   // one (tap, chunk) weight slice: BN rows x 128 B
         _Pragma("unroll") for (int p = 0; p < C::NS; ++p) {
-            const int piece = t + kThreads * p, n = piece >> 3, ch = piece & 7;
+            // LDS row j*16 + r of a wave's NS*16-row block holds output channel r*NS + j of that block: the NS
+            // accumulators of a lane are then NS consecutive channels and leave as one vector store per pixel
+            // (piece p of a thread is LDS row (t >> 3) + 64 p: the permutation only touches the thread's part)
+            const int row0 = t >> 3, ch = t & 7;
+            const int n = 64 * p + (row0 & (64 - C::NS * 16) & 63) + (row0 & 15) * C::NS + ((row0 >> 4) & (C::NS - 1));
             breg[p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, int((n * 9 * C::CIN + ch * PER) * ESZ),
                                                             int((tap * C::CIN + c0) * ESZ), 0);
         }
@@ -211,34 +234,39 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
             }
         }
 
-        // epilogue: bias + ReLU (+ lane-local 2x2 max-pool; max commutes with the monotone bias+ReLU)
-        _Pragma("unroll") for (int j = 0; j < C::NS; ++j) {
-            const int n = n0 + (wn * C::NS + j) * 16 + r;
-            const float b = bias[n];
+        // epilogue: bias + ReLU (+ lane-local 2x2 max-pool; max commutes with the monotone bias+ReLU). The lane's NS
+        // accumulators of a pixel are NS consecutive channels (see b_load): one vector store per pixel.
+        {
+            const int nb = n0 + (wn * 16 + r) * C::NS;
+            float bv[C::NS];
+            _Pragma("unroll") for (int j = 0; j < C::NS; ++j) bv[j] = bias[nb + j];
             if (C::POOL) {
                 _Pragma("unroll") for (int ip = 0; ip < kMS / 2; ++ip) {
-                    const f32x4 u = acc[2 * ip][j], d = acc[2 * ip + 1][j];
-                    const float p0 = fmaxf(fmaxf(u.x, u.y), fmaxf(d.x, d.y));
-                    const float p1 = fmaxf(fmaxf(u.z, u.w), fmaxf(d.z, d.w));
+                    float p0[C::NS], p1[C::NS];
+                    _Pragma("unroll") for (int j = 0; j < C::NS; ++j) {
+                        const f32x4 u = acc[2 * ip][j], d = acc[2 * ip + 1][j];
+                        p0[j] = fmaxf(fmaxf(fmaxf(u.x, u.y), fmaxf(d.x, d.y)) + bv[j], 0.f);
+                        p1[j] = fmaxf(fmaxf(fmaxf(u.z, u.w), fmaxf(d.z, d.w)) + bv[j], 0.f);
+                    }
                     const int yo = (y_tile + l_y0 + 2 * ip) >> 1;
                     const int img = img0 + (C::SEGW == 8 ? (q >> 1) : 0);
                     const int xo = C::SEGW == 8 ? 2 * (q & 1) : (((C::SEGS == 2 ? wm * 16 : 0) + 4 * q) >> 1);
                     if (img < n_img) {
-                        T* o = out + ((size_t(img) * C::HO + yo) * C::WO + xo) * C::COUT + n;
-                        store_elem<T>(o, fmaxf(p0 + b, 0.f));
-                        store_elem<T>(o + C::COUT, fmaxf(p1 + b, 0.f));
+                        T* o = out + ((size_t(img) * C::HO + yo) * C::WO + xo) * C::COUT + nb;
+                        store_vec<T, C::NS>(o, p0);
+                        store_vec<T, C::NS>(o + C::COUT, p1);
                     }
                 }
             } else {
                 _Pragma("unroll") for (int i = 0; i < kMS; ++i) {
                     const int y = y_tile + l_y0 + i;
-                    const float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
                     _Pragma("unroll") for (int e = 0; e < 4; ++e) {
+                        float v[C::NS];
+                        _Pragma("unroll") for (int j = 0; j < C::NS; ++j) v[j] = C::ACT ? fmaxf(acc[i][j][e] + bv[j], 0.f) : acc[i][j][e];
                         const int rr = 4 * q + e;
                         const int img = img0 + (C::SEGW == 8 ? (rr >> 3) : 0);
                         const int x = C::SEGW == 8 ? (rr & 7) : ((C::SEGS == 2 ? wm * 16 : 0) + rr);
-                        if (img < n_img)
-                            store_elem<T>(out + ((size_t(img) * C::H + y) * C::W + x) * C::COUT + n, C::ACT ? fmaxf(v[e] + b, 0.f) : v[e]);
+                        if (img < n_img) store_vec<T, C::NS>(out + ((size_t(img) * C::H + y) * C::W + x) * C::COUT + nb, v);
                     }
                 }
             }
