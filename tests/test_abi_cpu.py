@@ -113,3 +113,43 @@ def test_kernel_math_on_host_matches_oracle(hostsim, mk):
         assert ok, (name, worst)
         if name.startswith(("noise", "stereo", "silence")):       # broadband: log-domain bound
             assert np.abs(out - ref).max() <= 1e-4, name
+
+
+def test_argument_errors_are_reported_before_any_launch(L):
+    """Error behaviour of the C ABI (include/mla_hip.h): negative MLA_E_* codes + a message in mla_last_error(), decided on
+    the host before any HIP call -- so it is checkable without a GPU. Zero-sized work returns MLA_OK without touching
+    its (null) buffers, like the reference's functions on empty inputs."""
+    lib = L.lib()
+    lib.mla_last_error.restype = ctypes.c_char_p
+    vp = ctypes.c_void_p
+    fake = vp(0x1000)                                # aligned, never dereferenced: every call below fails validation first
+    E_ARG, E_SHAPE, E_SHORT, E_DTYPE = -1, -2, -3, -5
+
+    def expect(code, rc, needle=None):
+        assert rc == code, (rc, lib.mla_last_error())
+        if needle:
+            assert needle in lib.mla_last_error().decode(), lib.mla_last_error()
+
+    # front-end: reference raises ValueError for n < 240 (negative frame count)
+    expect(E_SHORT, lib.mla_logmel_examples(fake, L.F32, 1, 239, 239, fake, fake, L.F32, None), "239")
+    expect(E_DTYPE, lib.mla_logmel_examples(fake, 7, 1, 16000, 16000, fake, fake, L.F32, None))
+    expect(E_DTYPE, lib.mla_logmel_examples(fake, L.F32, 1, 16000, 16000, fake, fake, L.I16, None))
+    expect(E_ARG, lib.mla_logmel_examples(None, L.F32, 1, 16000, 16000, fake, fake, L.F32, None), "null")
+    expect(E_ARG, lib.mla_logmel_examples(fake, L.F32, 1, 16000, 15999, fake, fake, L.F32, None))      # stride < n_samples
+    expect(E_ARG, lib.mla_logmel_examples(fake, L.F32, 1, 16000, 16000, fake, vp(0x1004), L.F32, None))  # out misaligned
+    assert lib.mla_logmel_examples(None, L.F32, 0, 16000, 16000, None, None, L.F32, None) == 0          # no waveforms
+    assert lib.mla_logmel_examples(None, L.F32, 4, 15599, 15599, None, None, L.F32, None) == 0          # 0 examples each
+    expect(E_ARG, lib.mla_mono_mix(fake, L.F32, 100, 0, fake, None))
+    expect(E_DTYPE, lib.mla_mono_mix(fake, L.BF16, 100, 2, fake, None))
+    assert lib.mla_mono_mix(None, L.F32, 0, 2, None, None) == 0
+    # GEMM / conv
+    expect(E_ARG, lib.mla_linear(fake, 64, fake, 64, None, fake, 64, -1, 64, 64, L.F32, L.F32, 0, None))
+    expect(E_SHAPE, lib.mla_linear(fake, 66, fake, 66, None, fake, 64, 8, 64, 66, L.F32, L.F32, 0, None), "16-byte rows")
+    expect(E_DTYPE, lib.mla_linear(fake, 64, fake, 64, None, fake, 64, 8, 64, 64, L.F32, L.BF16, 0, None))
+    expect(E_ARG, lib.mla_linear(vp(0x1008), 64, fake, 64, None, fake, 64, 8, 64, 64, L.F32, L.F32, 0, None), "aligned")
+    assert lib.mla_linear(None, 64, None, 64, None, None, 64, 0, 64, 64, L.F32, L.F32, 0, None) == 0
+    expect(E_DTYPE, lib.mla_vggish_conv(2, fake, fake, fake, fake, 4, 9, None))
+    expect(E_ARG, lib.mla_vggish_conv(2, None, fake, fake, fake, 4, L.BF16, None))
+    assert lib.mla_vggish_conv(2, None, None, None, None, 0, L.BF16, None) == 0
+    rc = lib.mla_vggish_conv(9, fake, fake, fake, fake, 4, L.BF16, None)
+    assert rc in (E_ARG, E_SHAPE) and b"layer" in lib.mla_last_error()
