@@ -166,8 +166,24 @@ int dispatch(const void* a, int64_t lda, const void* w, int64_t ldw, const float
              int64_t M, int64_t N, int64_t K, bool relu, hipStream_t s) {
     const bool wide = N > 128 && (N % 256 == 0 || N % 256 > 128);     // 256-wide tiles unless they waste > half a tile
     const bool tall = wide && M >= 4096 && N >= 1024;                  // 256 x 256 tiles once they still fill the chip
-    if (tall) return relu ? launch<T, TO, 8, 4, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s)
-                          : launch<T, TO, 8, 4, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s);
+    if (tall) {
+        // Tile quantisation: 256 x 256 tiles run one per CU, so e.g. 640 tiles on 256 CUs take 3 rounds for 2.5 rounds of
+        // work. When the last round would be at most half full, the rows of the whole rounds keep the tall tiles and the
+        // remaining rows run as 128-row tiles (twice as many, same CUs busy): 2 + 0.5 rounds instead of 3.
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int64_t n_tiles = (N + 255) / 256, m_tiles = (M + 255) / 256;
+        const int64_t full_rounds = m_tiles * n_tiles / cus, rest = m_tiles * n_tiles - full_rounds * cus;
+        int64_t m_tall = M;
+        if (full_rounds >= 1 && rest > 0 && 2 * rest <= cus && (full_rounds * cus) % n_tiles == 0) m_tall = full_rounds * cus / n_tiles * 256;
+        int rc = relu ? launch<T, TO, 8, 4, true>(a, lda, w, ldw, bias, out, ldo, m_tall, N, K, s)
+                      : launch<T, TO, 8, 4, false>(a, lda, w, ldw, bias, out, ldo, m_tall, N, K, s);
+        if (rc != MLA_OK || m_tall == M) return rc;
+        const T* a2 = static_cast<const T*>(a) + m_tall * lda;
+        TO* out2 = static_cast<TO*>(out) + m_tall * ldo;
+        return relu ? launch<T, TO, 4, 4, true>(a2, lda, w, ldw, bias, out2, ldo, M - m_tall, N, K, s)
+                    : launch<T, TO, 4, 4, false>(a2, lda, w, ldw, bias, out2, ldo, M - m_tall, N, K, s);
+    }
     if (wide) return relu ? launch<T, TO, 4, 4, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s)
                           : launch<T, TO, 4, 4, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s);
     return relu ? launch<T, TO, 4, 2, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s)
