@@ -235,3 +235,33 @@ def test_hip_graph_replay_reproduces_eager_forward(model, W):
         assert torch.equal(g(pcm2).clone(), ens.forward_waveforms(pcm2))
     with pytest.raises(AssertionError):
         ens.train().capture_waveforms(pcm)
+
+
+def test_full_size_forward_properties(model, W):
+    """BASELINE config 3 at full size (1024 bags x 10 s -> 10 240 clips, bf16 conv/FC). The oracle cannot run this in
+    seconds, so size-independent properties: eval-mode bags are independent (a bag alone == the same bag inside the
+    batch, bit for bit: tile shape and batch position do not change any accumulation order), permuting bags permutes
+    the scores, reruns are deterministic; plus the oracle itself on two of the bags."""
+    from oracle import frontend as ofe, model as omodel
+    sd = W.make_state_dict(6, W.ensemble_shapes((2, 1), False))
+    ens = load(model.Ensemble("repeat", dict(CNN_CONF, just_bottlenecks=False), [2, 1], torch.device("cuda"), precision="bf16"), sd)
+    ens.eval()
+    base = torch.from_numpy(W.waveform(51, 160000, 32)).cuda()
+    pcm = base.repeat(32, 1).contiguous()                        # 1024 bags, 32 distinct
+    with torch.no_grad():
+        out = ens.forward_waveforms(pcm)
+        assert tuple(out.shape) == (1024, 10) and bool(torch.isfinite(out).all())
+        assert torch.equal(out, ens.forward_waveforms(pcm))
+        for rep in (1, 17, 31):
+            assert torch.equal(out[32 * rep:32 * rep + 32], out[:32])
+        assert torch.equal(ens.forward_waveforms(pcm[5:6]), out[5:6])           # one bag alone (different GEMM / grid shapes)
+        assert torch.equal(ens.forward_waveforms(pcm[:102]), out[:102])         # the 1 020-clip batch of the small-batch leg
+        perm = torch.randperm(1024, generator=torch.Generator().manual_seed(3)).cuda()
+        assert torch.equal(ens.forward_waveforms(pcm[perm].contiguous()), out[perm])
+        # oracle on two bags: bf16 deviation as measured elsewhere (< 5e-2 asserted, ~4e-3 typical)
+        waves = base[:2].cpu().numpy().astype(np.float64)
+        ex = torch.from_numpy(ofe.batch_examples(waves).astype(np.float32)).reshape(2, 10, 1, 96, 64)
+        ref = omodel.ensemble_forward({k: torch.as_tensor(v) for k, v in sd.items()}, ex, (2, 1), False)
+        assert rel_err(out[:2].cpu(), ref.numpy()) < 5e-2
+        ens.set_precision("f32")
+        assert rel_err(ens.forward_waveforms(pcm[:2]).cpu(), ref.numpy()) < 1e-4
