@@ -53,9 +53,8 @@ def build(force=False, verbose=True):
     objs = [o for o, _ in results]
     if any(changed for _, changed in results) or not os.path.exists(LIB):
         link = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
-        rccl = "/opt/rocm/lib/librccl.so"
-        if os.path.exists(rccl):
-            link += ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+        # no -lrccl: collectives go through torch.distributed (backend "nccl" = the RCCL build PyTorch ships); a second
+        # RCCL in the process (ROCm's) would only add two sets of nccl* symbols to the global namespace
         subprocess.run(link, check=True)
         if verbose:
             print("built", LIB)
