@@ -2,6 +2,7 @@
 """Headline benchmark: 0.96 s clips/s, wave -> class scores (VGGish + multi-level attention).
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --mode train [--finetune] ...          (BASELINE configs 4/5: the data-parallel train.py step)
 
 One step = one pass of the whole hot path over one batch of synthetic 16 kHz PCM that is
 already resident in HBM: fused log-mel front-end -> conv stack -> FC embeddings -> MLA head,
@@ -137,6 +138,62 @@ def h2d_leg(pcm, step_s, clips_per_step, reps=5):
             "pcm": str(pcm.dtype).replace("torch.", "") + ", pinned host memory"}
 
 
+def train_mode(args, world, rank, device):
+    """BASELINE configs 4 / 5: one step = zero_grad -> forward -> CrossEntropyLoss -> backward -> Adam (train.py:124-138)
+    on `bags` bags of 96 x 64 log-mel input per GPU (default 512; global batch = world x bags, 4096 at 8 GPUs), sharded by
+    bag. Per step the ranks exchange the BatchNorm sums (SyncBN: the step equals the reference's single-process step
+    on the global batch) and ONE flat-gradient all-reduce over RCCL. Frozen CNN (the reference default) unless
+    --finetune; CNN precision from --precision (finetune: f32)."""
+    import torch.distributed as dist
+    W = importlib.import_module(PKG + ".weights")
+    M = importlib.import_module(PKG + ".model")
+    TR = importlib.import_module(PKG + ".train")
+    bags = args.bags if args.bags != 1024 else 512
+    precision = "f32" if args.finetune else args.precision
+    ens = M.Ensemble("repeat", CNN_CONF, [2, 1], device, precision=precision)
+    ens.load_state_dict({k: torch.as_tensor(v) for k, v in W.make_state_dict(7, W.ensemble_shapes((2, 1), False)).items()})
+    ens.to(device)
+    if args.finetune:
+        M.set_requires_grad(ens, True)
+    step = TR.TrainStep(ens, lr=1e-4 if args.finetune else 1e-3)
+    x = torch.from_numpy(W.uniform(4000 + rank, 1, bags * T_BAG * 96 * 64, lo=-1.4, hi=4.6)).reshape(bags, T_BAG, 1, 96, 64).to(device)
+    y = torch.from_numpy(W.bits24(4000 + rank, 2, bags) % 10).to(device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss, _ = step(x, y)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step(x, y)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        clips = bags * T_BAG
+        assert bool(torch.isfinite(loss))
+        print(json.dumps({
+            "metric": "0.96 s clips/sec train step fwd+bwd+Adam (VGGish+attn)", "value": world * clips * args.steps / elapsed,
+            "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": precision, "data": "synthetic",
+            "config": {"workload": "BASELINE config %s: train.py step on %d bags x 10 x (96 x 64) log-mel per GPU, %s, Adam lr %g, "
+                                   "MLA [2,1]; SyncBN sums + one flat-gradient all-reduce (%d floats) per step"
+                                   % ("5" if world > 1 else "4", bags, "finetune (all parameters)" if args.finetune else "frozen CNN (reference default)",
+                                      step.lr, step.n_params),
+                       "bags_per_gpu": bags, "global_batch_bags": world * bags, "parallelism": "dp%d" % world},
+            "loss_last": float(loss)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +201,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bags", type=int, default=1024, help="bags (10 s waveforms) per GPU per step")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="infer (default, the headline metric) or train: BASELINE configs 4/5, the data-parallel train.py step")
+    ap.add_argument("--finetune", action="store_true", help="--mode train: every parameter trainable (f32), train.py:96-97")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the 1 020-clip eager / HIP-graph leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse N>1 on one GPU)")
@@ -168,6 +228,8 @@ def main():
     importlib.import_module(PKG + ".build").build(verbose=False) if rank == 0 and not os.path.exists(
         os.path.join(ROOT, PKG, "libmla_hip.so")) else None
     ops = importlib.import_module(PKG + ".ops")
+    if args.mode == "train":
+        return train_mode(args, world, rank, device)
     ens, sd = build_model(args.precision, device)
     pcm = synth_pcm(args.bags, rank, device)
     clips_per_step = args.bags * T_BAG
