@@ -1,4 +1,4 @@
-"""Calibration only (never on the product path): the oracle's torch restatement of the reference model run by PyTorch-ROCm
+"""Calibration only (test infrastructure, lives under tests/ because it uses the oracle; never on the product path): the oracle's torch restatement of the reference model run by PyTorch-ROCm
 eager on the GPU (MIOpen convolutions, hipBLASLt/rocBLAS linears) -- i.e. what the reference's own model code costs on
 this hardware, examples -> scores, f32 and bf16 autocast. First calls include MIOpen's kernel search (minutes)."""
 import importlib, os, sys, time, json
