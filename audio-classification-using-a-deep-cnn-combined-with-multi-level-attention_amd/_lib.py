@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MLA_HIP_LIB") or os.path.join(HERE, "libmla_hip.so")   # MLA_HIP_LIB: an alternative build (A/B measurements)
 HEADER = os.path.join(os.path.dirname(HERE), "include", "mla_hip.h")
 
-F32, BF16, I16 = 0, 1, 2
+F32, BF16, I16, BF16X3 = 0, 1, 2, 3
 E_SHORT = -3
 
 _lib = None
@@ -52,6 +52,9 @@ def lib():
         L.mla_dataset_frames.argtypes = [vp, i64, ci, ci, ci, ci, vp, vp]
         L.mla_postprocess.argtypes = [vp, vp, vp, i64, vp, vp]
         L.mla_mono_mix.argtypes = [vp, ci, i64, ci, vp, vp]
+        L.mla_split_bf16x3.argtypes = [vp, i64, i64, i64, vp, i64, i64, ci, vp]
+        L.mla_merge_bf16x3.argtypes = [vp, i64, i64, i64, i64, vp, vp]
+        L.mla_linear_bf16x3.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i64, ci, ci, vp]
         L.mla_conv_repack_weights.argtypes = [vp, i64, i64, vp, ci, vp]
         L.mla_convert_f32.argtypes = [vp, vp, i64, ci, vp]
         L.mla_convert_bf16_to_f32.argtypes = [vp, vp, i64, vp]

@@ -31,12 +31,21 @@ using namespace mma;
 
 constexpr int kThreads = 512, kWavesN = 4, kMS = 6;
 
-template <typename T, int CIN_, int COUT_, int H_, int W_, bool POOL_, int NS_, bool ACT_ = true>
+// SPLIT ("bf16x3"): every f32 value x travels as two bf16, hi = bf16(x) and lo = bf16(x - hi) (x = hi + lo to 2^-18
+// relative). Activations hold [hi(C) | lo(C)] per pixel, repacked weights [hi(Cin) | lo(Cin) | hi(Cin)] per tap, and
+// the K loop runs the three products a_hi w_hi + a_hi w_lo + a_lo w_hi (bf16 products are exact in the f32 accumulator;
+// the dropped a_lo w_lo is 2^-18 relative): f32-grade results at a third of the bf16 MFMA rate.
+template <typename T, int CIN_, int COUT_, int H_, int W_, bool POOL_, int NS_, bool ACT_ = true, bool SPLIT_ = false>
 struct Cfg {
     using elem = T;
     static constexpr int CIN = CIN_, COUT = COUT_, H = H_, W = W_, NS = NS_;
     static constexpr bool POOL = POOL_;
     static constexpr bool ACT = ACT_;                       // epilogue: bias + ReLU (forward) or plain store (dgrad)
+    static constexpr bool SPLIT = SPLIT_;
+    static constexpr int CIN_A = SPLIT ? 2 * CIN : CIN;     // channels per input pixel in memory
+    static constexpr int CIN_W = SPLIT ? 3 * CIN : CIN;     // channels per tap of the repacked weights = K per tap
+    static constexpr int COUT_MEM = SPLIT ? 2 * COUT : COUT;
+    static_assert(!SPLIT || (sizeof(T) == 2 && ACT_), "the split mode is a bf16 forward mode");
     static constexpr int SEGW = W >= 16 ? 16 : 8;          // pixels of one image row per m-subtile
     static constexpr int SEGS = W / SEGW;                   // subtiles per tile row (2 for W = 32)
     static constexpr int IMGS = 16 / SEGW;                  // images per tile (2 for W = 8)
@@ -48,7 +57,8 @@ struct Cfg {
     static constexpr int B_BYTES = BN * kRowBytes;
     static constexpr int LDS_BYTES = A_BYTES + 2 * B_BYTES;
     static constexpr int TILES_Y = H / TH;
-    static constexpr bool PERSIST = NS > 2;                 // conv2 (half-width tile): two non-persistent workgroups per CU
+    static constexpr bool PERSIST = NS > 2 || SPLIT;        // conv2 (half-width tile): two non-persistent workgroups per CU
+                                                            // (its split form has a 3x longer K loop and more epilogue registers)
     static constexpr int MIN_WAVES = (PERSIST || sizeof(T) == 4) ? 2 : 4;      // waves per SIMD the register budget is held to
     static constexpr int HO = POOL ? H / 2 : H, WO = POOL ? W / 2 : W;
     static_assert(W == 32 || W == 16 || W == 8, "tile mapping covers the VGGish widths");
@@ -75,6 +85,23 @@ template <> __device__ __forceinline__ void store_vec<bf16_t, 2>(bf16_t* p, cons
 
 template <> __device__ __forceinline__ void store_vec<float, 1>(float* p, const float* v) { *p = v[0]; }
 template <> __device__ __forceinline__ void store_vec<bf16_t, 1>(bf16_t* p, const float* v) { p->bits = f2bf(v[0]); }
+
+// the lane's NS channels of one output pixel: one vector store, or (SPLIT) the hi plane and the lo plane COUT apart
+template <typename C>
+__device__ __forceinline__ void store_px(typename C::elem* p, const float* v) {
+    using T = typename C::elem;
+    if constexpr (C::SPLIT) {
+        float hi[C::NS], lo[C::NS];
+        _Pragma("unroll") for (int j = 0; j < C::NS; ++j) {
+            hi[j] = bf2f(f2bf(v[j]));
+            lo[j] = v[j] - hi[j];
+        }
+        store_vec<T, C::NS>(p, hi);                 // exact: hi is a bf16 value
+        store_vec<T, C::NS>(p + C::COUT, lo);
+    } else {
+        store_vec<T, C::NS>(p, v);
+    }
+}
 
 template <typename C>
 __device__ __forceinline__ int a_swizzle(int xh, int img) {
@@ -122,7 +149,10 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
 
     constexpr int A_PIECES = C::IMGS * C::PH * C::PW * 8;
     constexpr int A_PASSES = (A_PIECES + kThreads - 1) / kThreads;
-    constexpr int CHUNKS = C::CIN / C::KC;
+    constexpr int CHUNKS = C::CIN_W / C::KC;                // K chunks per tap (three passes over the input planes when SPLIT)
+    constexpr int PLANE = C::CIN / C::KC;                    // chunks per input plane
+    // input channel offset that pairs with weight chunk c: [a_hi | a_hi | a_lo] against [w_hi | w_lo | w_hi]
+    auto a_chan = [](int c) { return (!C::SPLIT || c < 2 * PLANE ? c % PLANE : c - PLANE) * C::KC; };
 
     // Global operands through buffer descriptors (wave-uniform base, 32-bit per-lane offsets fixed
     // for the whole kernel, scalar offset per tap / chunk). Out-of-image halo pixels and images past
@@ -130,12 +160,12 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
     constexpr uint32_t ESZ = sizeof(T);
     auto patch_rsrc = [&](int first_img) {     // descriptor over the tile's images (fewer at the batch tail)
         const int imgs_here = (n_img - first_img) < C::IMGS ? (n_img - first_img) : C::IMGS;
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in) + size_t(first_img) * C::H * C::W * C::CIN, 0,
-                                                 uint32_t(imgs_here) * C::H * C::W * C::CIN * ESZ, 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in) + size_t(first_img) * C::H * C::W * C::CIN_A, 0,
+                                                 uint32_t(imgs_here) * C::H * C::W * C::CIN_A * ESZ, 0x00020000);
     };
     __amdgpu_buffer_rsrc_t a_rsrc = patch_rsrc(img0);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>(wgt) + size_t(n0) * 9 * C::CIN, 0, uint32_t(C::BN) * 9 * C::CIN * ESZ, 0x00020000);
+        const_cast<T*>(wgt) + size_t(n0) * 9 * C::CIN_W, 0, uint32_t(C::BN) * 9 * C::CIN_W * ESZ, 0x00020000);
     // Per-lane offsets are recomputed where they are used (once per chunk for the patch, ~2 VALU per
     // weight piece) instead of being held in VGPRs across the MFMA loop: registers are the scarce
     // resource here (96 accumulators + 40 fragment + 36 staging registers per lane).
@@ -148,7 +178,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
             const int yh = rest % C::PH, im = rest / C::PH;
             const int gy = y_tile + yh - 1, gx = xh - 1;
             const bool ok = piece < A_PIECES && gy >= 0 && gy < C::H && gx >= 0 && gx < C::W;
-            const int voff = ok ? int((((im * C::H + gy) * C::W + gx) * C::CIN + ch * PER) * ESZ) : int(0x7fffff00);
+            const int voff = ok ? int((((im * C::H + gy) * C::W + gx) * C::CIN_A + ch * PER) * ESZ) : int(0x7fffff00);
             apre[p] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, voff, int(c0 * ESZ), 0);
         }
     };
@@ -170,8 +200,8 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
             // (piece p of a thread is LDS row (t >> 3) + 64 p: the permutation only touches the thread's part)
             const int row0 = t >> 3, ch = t & 7;
             const int n = 64 * p + (row0 & (64 - C::NS * 16) & 63) + (row0 & 15) * C::NS + ((row0 >> 4) & (C::NS - 1));
-            breg[p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, int((n * 9 * C::CIN + ch * PER) * ESZ),
-                                                            int((tap * C::CIN + c0) * ESZ), 0);
+            breg[p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, int((n * 9 * C::CIN_W + ch * PER) * ESZ),
+                                                            int((tap * C::CIN_W + c0) * ESZ), 0);
         }
     };
     auto b_write = [&](int buf_off) {
@@ -207,7 +237,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                 else if (more) b_load(last_chunk ? 0 : c0 + C::KC, 0);
                 if (tap == 5 && more) {
                     if (last_chunk) a_rsrc = patch_rsrc((next_tile / C::TILES_Y) * C::IMGS);
-                    a_load(last_chunk ? 0 : c0 + C::KC);
+                    a_load(last_chunk ? 0 : a_chan(c + 1));
                 }
                 _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {
                     u32x4 af[kMS], bf[C::NS];
@@ -252,9 +282,9 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                     const int img = img0 + (C::SEGW == 8 ? (q >> 1) : 0);
                     const int xo = C::SEGW == 8 ? 2 * (q & 1) : (((C::SEGS == 2 ? wm * 16 : 0) + 4 * q) >> 1);
                     if (img < n_img) {
-                        T* o = out + ((size_t(img) * C::HO + yo) * C::WO + xo) * C::COUT + nb;
-                        store_vec<T, C::NS>(o, p0);
-                        store_vec<T, C::NS>(o + C::COUT, p1);
+                        T* o = out + ((size_t(img) * C::HO + yo) * C::WO + xo) * C::COUT_MEM + nb;
+                        store_px<C>(o, p0);
+                        store_px<C>(o + C::COUT_MEM, p1);
                     }
                 }
             } else {
@@ -266,7 +296,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                         const int rr = 4 * q + e;
                         const int img = img0 + (C::SEGW == 8 ? (rr >> 3) : 0);
                         const int x = C::SEGW == 8 ? (rr & 7) : ((C::SEGS == 2 ? wm * 16 : 0) + rr);
-                        if (img < n_img) store_vec<T, C::NS>(out + ((size_t(img) * C::H + y) * C::W + x) * C::COUT + nb, v);
+                        if (img < n_img) store_px<C>(out + ((size_t(img) * C::H + y) * C::W + x) * C::COUT_MEM + nb, v);
                     }
                 }
             }
@@ -292,7 +322,7 @@ template <typename T> struct Conv1Frag;
 template <> struct Conv1Frag<bf16_t> { u32x4 b[4]; };           // B[k = 8q + e][n = 16 j + r], bf16 pairs
 template <> struct Conv1Frag<float> { float b[3][4]; };         // B[k = 4 s + q][n = 16 j + r]
 
-template <typename TIN, typename T>
+template <typename TIN, typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256, 4) void conv1_kernel(const TIN* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ bias, T* __restrict__ out, int n_img) {
     constexpr int PITCH = 68;                                   // floats per patch row (66 used)
@@ -383,8 +413,17 @@ __global__ __launch_bounds__(256, 4) void conv1_kernel(const TIN* __restrict__ x
             const float p0 = fmaxf(fmaxf(fmaxf(u.x, u.y), fmaxf(d.x, d.y)) + bj[j], 0.f);
             const float p1 = fmaxf(fmaxf(fmaxf(u.z, u.w), fmaxf(d.z, d.w)) + bj[j], 0.f);
             const int xo = 8 * seg + 2 * q;
-            store_elem<T>(reinterpret_cast<T*>(stage + xo * ROW) + 16 * j + r, p0);
-            store_elem<T>(reinterpret_cast<T*>(stage + (xo + 1) * ROW) + 16 * j + r, p1);
+            if constexpr (SPLIT) {        // f32 arithmetic, [hi(64) | lo(64)] bf16 per pooled pixel = the f32 row's 256 bytes
+                static_assert(!SPLIT || sizeof(T) == 4, "split output is produced by the exact-f32 path");
+                bf16_t* s0 = reinterpret_cast<bf16_t*>(stage + xo * ROW) + 16 * j + r;
+                bf16_t* s1 = reinterpret_cast<bf16_t*>(stage + (xo + 1) * ROW) + 16 * j + r;
+                const float h0 = bf2f(f2bf(p0)), h1 = bf2f(f2bf(p1));
+                s0[0].bits = f2bf(h0); s0[64].bits = f2bf(p0 - h0);
+                s1[0].bits = f2bf(h1); s1[64].bits = f2bf(p1 - h1);
+            } else {
+                store_elem<T>(reinterpret_cast<T*>(stage + xo * ROW) + 16 * j + r, p0);
+                store_elem<T>(reinterpret_cast<T*>(stage + (xo + 1) * ROW) + 16 * j + r, p1);
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the stage rows belong to this wave only:
@@ -455,6 +494,17 @@ int conv_layer(int layer, const void* in, const void* w, const float* bias, void
         case 4: return launch_conv<Cfg<T, 256, 256, 24, 16, true, 4>>(in, w, bias, out, n, s);
         case 5: return launch_conv<Cfg<T, 256, 512, 12, 8, false, 4>>(in, w, bias, out, n, s);
         case 6: return launch_conv<Cfg<T, 512, 512, 12, 8, true, 4>>(in, w, bias, out, n, s);
+    }
+    return mla::fail(MLA_E_SHAPE, "conv layer %d is not one of VGGish conv2..conv6", layer);
+}
+
+int conv_layer_split(int layer, const void* in, const void* w, const float* bias, void* out, int64_t n, hipStream_t s) {
+    switch (layer) {
+        case 2: return launch_conv<Cfg<bf16_t, 64, 128, 48, 32, true, 2, true, true>>(in, w, bias, out, n, s);
+        case 3: return launch_conv<Cfg<bf16_t, 128, 256, 24, 16, false, 4, true, true>>(in, w, bias, out, n, s);
+        case 4: return launch_conv<Cfg<bf16_t, 256, 256, 24, 16, true, 4, true, true>>(in, w, bias, out, n, s);
+        case 5: return launch_conv<Cfg<bf16_t, 256, 512, 12, 8, false, 4, true, true>>(in, w, bias, out, n, s);
+        case 6: return launch_conv<Cfg<bf16_t, 512, 512, 12, 8, true, 4, true, true>>(in, w, bias, out, n, s);
     }
     return mla::fail(MLA_E_SHAPE, "conv layer %d is not one of VGGish conv2..conv6", layer);
 }
@@ -542,6 +592,60 @@ extern "C" int mla_convert_f32(const float* in, void* out, int64_t n, int dtype,
     return MLA_OK;
 }
 
+// f32 (rows, cols) -> bf16 planes per segment of `seg` columns: [hi | lo] (copies = 2, activations) or [hi | lo | hi]
+// (copies = 3, weights of the bf16x3 mode); out row pitch ld_out >= copies * cols.
+__global__ void split_kernel(const float* __restrict__ in, int64_t rows, int64_t cols, int64_t ld_in, bf16_t* __restrict__ out,
+                             int64_t ld_out, int64_t seg, int copies) {
+    const int64_t total = rows * cols;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t r = i / cols, c = i - r * cols, sidx = c / seg, within = c - sidx * seg;
+        const float x = in[r * ld_in + c];
+        const float hi = bf2f(f2bf(x));
+        bf16_t* o = out + r * ld_out + sidx * copies * seg + within;
+        o[0].bits = f2bf(hi);
+        o[seg].bits = f2bf(x - hi);
+        if (copies == 3) o[2 * seg].bits = f2bf(hi);
+    }
+}
+
+extern "C" int mla_split_bf16x3(const float* in, int64_t rows, int64_t cols, int64_t ld_in, void* out, int64_t ld_out,
+                                int64_t seg, int copies, mla_stream_t stream) {
+    MLA_REQUIRE(rows >= 0 && cols > 0 && seg > 0 && cols % seg == 0 && (copies == 2 || copies == 3) && ld_in >= cols &&
+                ld_out >= copies * cols, MLA_E_ARG, "bad split arguments (rows %lld cols %lld seg %lld copies %d)",
+                (long long)rows, (long long)cols, (long long)seg, copies);
+    if (rows == 0) return MLA_OK;
+    MLA_REQUIRE(in && out, MLA_E_ARG, "null split buffers");
+    const int64_t total = rows * cols;
+    const unsigned grid = unsigned((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(split_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), in, rows, cols, ld_in,
+                       static_cast<bf16_t*>(out), ld_out, seg, copies);
+    MLA_LAUNCH_OK("split_kernel");
+    return MLA_OK;
+}
+
+__global__ void merge_kernel(const bf16_t* __restrict__ in, int64_t rows, int64_t cols, int64_t ld_in, int64_t seg,
+                             float* __restrict__ out) {
+    const int64_t total = rows * cols;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t r = i / cols, c = i - r * cols, sidx = c / seg, within = c - sidx * seg;
+        const bf16_t* p = in + r * ld_in + sidx * 2 * seg + within;
+        out[i] = bf2f(p[0].bits) + bf2f(p[seg].bits);
+    }
+}
+
+extern "C" int mla_merge_bf16x3(const void* in, int64_t rows, int64_t cols, int64_t ld_in, int64_t seg, float* out,
+                                mla_stream_t stream) {
+    MLA_REQUIRE(rows >= 0 && cols > 0 && seg > 0 && cols % seg == 0 && ld_in >= 2 * cols, MLA_E_ARG, "bad merge arguments");
+    if (rows == 0) return MLA_OK;
+    MLA_REQUIRE(in && out, MLA_E_ARG, "null merge buffers");
+    const int64_t total = rows * cols;
+    const unsigned grid = unsigned((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(merge_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(in),
+                       rows, cols, ld_in, seg, out);
+    MLA_LAUNCH_OK("merge_kernel");
+    return MLA_OK;
+}
+
 extern "C" int mla_convert_bf16_to_f32(const void* in, float* out, int64_t n, mla_stream_t stream) {
     MLA_REQUIRE(in && out && n >= 0, MLA_E_ARG, "bad convert arguments");
     if (n == 0) return MLA_OK;
@@ -557,8 +661,9 @@ extern "C" int mla_vggish_conv1(const void* x, int x_dtype, int64_t n, const flo
     MLA_REQUIRE(n >= 0, MLA_E_ARG, "n %lld", (long long)n);
     if (n == 0) return MLA_OK;
     MLA_REQUIRE(x && w && bias && out && mla::aligned(out, 16), MLA_E_ARG, "null / misaligned conv1 buffers");
-    MLA_REQUIRE((x_dtype == MLA_F32 || x_dtype == MLA_BF16) && (dtype == MLA_F32 || dtype == MLA_BF16), MLA_E_DTYPE,
-                "conv1 dtypes %d -> %d", x_dtype, dtype);
+    MLA_REQUIRE((x_dtype == MLA_F32 || x_dtype == MLA_BF16) && (dtype == MLA_F32 || dtype == MLA_BF16 || dtype == MLA_BF16X3),
+                MLA_E_DTYPE, "conv1 dtypes %d -> %d", x_dtype, dtype);
+    MLA_REQUIRE(dtype != MLA_BF16X3 || x_dtype == MLA_F32, MLA_E_DTYPE, "the split output is computed from float32 examples");
     MLA_REQUIRE(n * 12 <= 0x7fffffff, MLA_E_SHAPE, "batch too large");
     int dev1 = 0, cus1 = 256;
     if (hipGetDevice(&dev1) == hipSuccess) hipDeviceGetAttribute(&cus1, hipDeviceAttributeMultiprocessorCount, dev1);
@@ -566,7 +671,9 @@ extern "C" int mla_vggish_conv1(const void* x, int x_dtype, int64_t n, const flo
     const int n_pix = int(n);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 g{unsigned(blocks)}, b{256};
-    if (x_dtype == MLA_F32 && dtype == MLA_F32)
+    if (dtype == MLA_BF16X3)
+        hipLaunchKernelGGL((conv1_kernel<float, float, true>), g, b, 0, s, static_cast<const float*>(x), w, bias, static_cast<float*>(out), n_pix);
+    else if (x_dtype == MLA_F32 && dtype == MLA_F32)
         hipLaunchKernelGGL((conv1_kernel<float, float>), g, b, 0, s, static_cast<const float*>(x), w, bias, static_cast<float*>(out), n_pix);
     else if (x_dtype == MLA_F32)
         hipLaunchKernelGGL((conv1_kernel<float, bf16_t>), g, b, 0, s, static_cast<const float*>(x), w, bias, static_cast<bf16_t*>(out), n_pix);
@@ -587,5 +694,6 @@ extern "C" int mla_vggish_conv(int layer, const void* in, const void* w_repacked
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == MLA_F32) return conv_layer<float>(layer, in, w_repacked, bias, out, n, s);
     if (dtype == MLA_BF16) return conv_layer<bf16_t>(layer, in, w_repacked, bias, out, n, s);
+    if (dtype == MLA_BF16X3) return conv_layer_split(layer, in, w_repacked, bias, out, n, s);
     return mla::fail(MLA_E_DTYPE, "conv dtype %d", dtype);
 }

@@ -21,7 +21,8 @@ template <typename T, typename TO, int MS, int NS, bool RELU>
 __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__ A, int64_t lda,
                                                             const T* __restrict__ W, int64_t ldw,
                                                             const float* __restrict__ bias, TO* __restrict__ out,
-                                                            int64_t ldo, int M, int N, int K, float* __restrict__ partial) {
+                                                            int64_t ldo, int M, int N, int K, float* __restrict__ partial,
+                                                            int seg, int osplit) {
     constexpr int PER = Elem<T>::kPerChunk, KC = Elem<T>::kPerRow;
     constexpr int kMS = MS, kBM = 2 * MS * 16;                  // 2 (M) x 4 (N) waves: tile (32 MS) x (64 NS)
     constexpr int BN = 4 * NS * 16;
@@ -42,12 +43,19 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
         _Pragma("unroll") for (int j = 0; j < NS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     u32x4 areg[AP], breg[NS];
+    // seg > 0 ("bf16x3", see conv.hip): W holds [w_hi | w_lo | w_hi] per segment of `seg` K-chunks and A [a_hi | a_lo];
+    // weight stage s = 3 seg b + r pairs with activation stage 2 seg b + (r < seg ? r : r - seg). K counts W columns.
     auto gload = [&](int s) {
+        int sa = s;
+        if (seg) {
+            const int blk = s / (3 * seg), rr = s - blk * 3 * seg;
+            sa = blk * 2 * seg + (rr < seg ? rr : rr - seg);
+        }
         _Pragma("unroll") for (int p = 0; p < AP; ++p) {
             const int piece = t + kThreads * p, row = piece >> 3, ch = piece & 7;
-            const int k = s * KC + ch * PER;
+            const int k = sa * KC + ch * PER;
             areg[p] = zero16();
-            if (m0 + row < M && k < K) areg[p] = *reinterpret_cast<const u32x4*>(A + size_t(m0 + row) * lda + k);
+            if (m0 + row < M && s * KC + ch * PER < K) areg[p] = *reinterpret_cast<const u32x4*>(A + size_t(m0 + row) * lda + k);
         }
         _Pragma("unroll") for (int p = 0; p < NS; ++p) {
             const int piece = t + kThreads * p, n = piece >> 3, ch = piece & 7;
@@ -119,7 +127,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
                 if (m < M) {
                     float y = v[e] + b;
                     if (RELU) y = fmaxf(y, 0.f);
-                    store_elem<TO>(out + size_t(m) * ldo + n, y);
+                    if (sizeof(TO) == 2 && osplit) {              // [hi(N) | lo(N)] row of 2 N bf16
+                        const float hi = bf2f(f2bf(y));
+                        store_elem<TO>(out + size_t(m) * ldo + n, hi);
+                        store_elem<TO>(out + size_t(m) * ldo + N + n, y - hi);
+                    } else {
+                        store_elem<TO>(out + size_t(m) * ldo + n, y);
+                    }
                 }
             }
         }
@@ -143,14 +157,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 template <typename T, typename TO, int MS, int NS, bool RELU>
 int launch(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* out, int64_t ldo,
-           int64_t M, int64_t N, int64_t K, hipStream_t s, int splits = 1, float* partial = nullptr) {
+           int64_t M, int64_t N, int64_t K, hipStream_t s, int splits = 1, float* partial = nullptr, int seg = 0, int osplit = 0) {
     constexpr int kBM = 2 * MS * 16, BN = 4 * NS * 16;
     constexpr int lds = 2 * (kBM + BN) * kRowBytes;
     auto kern = gemm_kernel<T, TO, MS, NS, RELU>;
     MLA_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const dim3 grid{unsigned((M + kBM - 1) / kBM), unsigned((N + BN - 1) / BN), unsigned(splits)};
     hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, static_cast<const T*>(a), lda, static_cast<const T*>(w), ldw,
-                       bias, static_cast<TO*>(out), ldo, int(M), int(N), int(K), splits > 1 ? partial : nullptr);
+                       bias, static_cast<TO*>(out), ldo, int(M), int(N), int(K), splits > 1 ? partial : nullptr, seg, osplit);
     MLA_LAUNCH_OK("gemm_kernel");
     if (splits > 1) {
         const int64_t total = M * N;
@@ -163,7 +177,7 @@ int launch(const void* a, int64_t lda, const void* w, int64_t ldw, const float* 
 
 template <typename T, typename TO>
 int dispatch(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* out, int64_t ldo,
-             int64_t M, int64_t N, int64_t K, bool relu, hipStream_t s) {
+             int64_t M, int64_t N, int64_t K, bool relu, hipStream_t s, int seg = 0, int osplit = 0) {
     const bool wide = N > 128 && (N % 256 == 0 || N % 256 > 128);     // 256-wide tiles unless they waste > half a tile
     const bool tall = wide && M >= 4096 && N >= 1024;                  // 256 x 256 tiles once they still fill the chip
     if (tall) {
@@ -176,18 +190,18 @@ int dispatch(const void* a, int64_t lda, const void* w, int64_t ldw, const float
         const int64_t full_rounds = m_tiles * n_tiles / cus, rest = m_tiles * n_tiles - full_rounds * cus;
         int64_t m_tall = M;
         if (full_rounds >= 1 && rest > 0 && 2 * rest <= cus && (full_rounds * cus) % n_tiles == 0) m_tall = full_rounds * cus / n_tiles * 256;
-        int rc = relu ? launch<T, TO, 8, 4, true>(a, lda, w, ldw, bias, out, ldo, m_tall, N, K, s)
-                      : launch<T, TO, 8, 4, false>(a, lda, w, ldw, bias, out, ldo, m_tall, N, K, s);
+        int rc = relu ? launch<T, TO, 8, 4, true>(a, lda, w, ldw, bias, out, ldo, m_tall, N, K, s, 1, nullptr, seg, osplit)
+                      : launch<T, TO, 8, 4, false>(a, lda, w, ldw, bias, out, ldo, m_tall, N, K, s, 1, nullptr, seg, osplit);
         if (rc != MLA_OK || m_tall == M) return rc;
         const T* a2 = static_cast<const T*>(a) + m_tall * lda;
         TO* out2 = static_cast<TO*>(out) + m_tall * ldo;
-        return relu ? launch<T, TO, 4, 4, true>(a2, lda, w, ldw, bias, out2, ldo, M - m_tall, N, K, s)
-                    : launch<T, TO, 4, 4, false>(a2, lda, w, ldw, bias, out2, ldo, M - m_tall, N, K, s);
+        return relu ? launch<T, TO, 4, 4, true>(a2, lda, w, ldw, bias, out2, ldo, M - m_tall, N, K, s, 1, nullptr, seg, osplit)
+                    : launch<T, TO, 4, 4, false>(a2, lda, w, ldw, bias, out2, ldo, M - m_tall, N, K, s, 1, nullptr, seg, osplit);
     }
-    if (wide) return relu ? launch<T, TO, 4, 4, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s)
-                          : launch<T, TO, 4, 4, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s);
-    return relu ? launch<T, TO, 4, 2, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s)
-                : launch<T, TO, 4, 2, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s);
+    if (wide) return relu ? launch<T, TO, 4, 4, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit)
+                          : launch<T, TO, 4, 4, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit);
+    return relu ? launch<T, TO, 4, 2, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit)
+                : launch<T, TO, 4, 2, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit);
 }
 
 }  // namespace
@@ -226,4 +240,25 @@ extern "C" int mla_linear(const void* a, int64_t lda, const void* w, int64_t ldw
     if (dtype == MLA_F32) return dispatch<float, float>(a, lda, w, ldw, bias, out, ldo, M, N, K, relu != 0, s);
     if (out_dtype == MLA_F32) return dispatch<mma::bf16_t, float>(a, lda, w, ldw, bias, out, ldo, M, N, K, relu != 0, s);
     return dispatch<mma::bf16_t, mma::bf16_t>(a, lda, w, ldw, bias, out, ldo, M, N, K, relu != 0, s);
+}
+
+// "bf16x3" Linear (see MLA_BF16X3): a (M, 2K) = [hi | lo] per segment of `seg` columns, w (N, 3K) = [w_hi | w_lo | w_hi] per
+// segment (mla_split_bf16x3), K = logical reduction length. out: float32 (M, N), or split bf16 (M, 2N) = [hi(N) | lo(N)].
+extern "C" int mla_linear_bf16x3(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* out,
+                                 int64_t ldo, int64_t M, int64_t N, int64_t K, int64_t seg, int out_dtype, int relu,
+                                 mla_stream_t stream) {
+    MLA_REQUIRE(M >= 0 && N > 0 && K > 0, MLA_E_ARG, "bad GEMM shape %lld x %lld x %lld", (long long)M, (long long)N, (long long)K);
+    if (M == 0) return MLA_OK;
+    MLA_REQUIRE(a && w && out, MLA_E_ARG, "null GEMM operand");
+    MLA_REQUIRE(out_dtype == MLA_F32 || out_dtype == MLA_BF16X3, MLA_E_DTYPE, "split GEMM out dtype %d", out_dtype);
+    MLA_REQUIRE(seg > 0 && seg % 64 == 0 && K % seg == 0 && lda >= 2 * K && ldw >= 3 * K && lda % 8 == 0 && ldw % 8 == 0 &&
+                ldo >= (out_dtype == MLA_F32 ? N : 2 * N), MLA_E_SHAPE,
+                "split GEMM: seg %lld must be a multiple of 64 dividing K %lld; lda %lld >= 2K, ldw %lld >= 3K", (long long)seg,
+                (long long)K, (long long)lda, (long long)ldw);
+    MLA_REQUIRE(mla::aligned(a, 16) && mla::aligned(w, 16), MLA_E_ARG, "GEMM operands must be 16-byte aligned");
+    MLA_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && 3 * K < (1ll << 31), MLA_E_SHAPE, "GEMM dimension overflow");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (out_dtype == MLA_F32)
+        return dispatch<mma::bf16_t, float>(a, lda, w, ldw, bias, out, ldo, M, N, 3 * K, relu != 0, s, int(seg / 64), 0);
+    return dispatch<mma::bf16_t, mma::bf16_t>(a, lda, w, ldw, bias, out, ldo, M, N, 3 * K, relu != 0, s, int(seg / 64), 1);
 }

@@ -172,7 +172,7 @@ class CNN(nn.Module):
     def forward(self, x):
         x = self.cnn_model(x)
         if x.dtype == torch.bfloat16:      # bf16 bottlenecks (just_bottlenecks=True) feed the f32 head
-            x = ops.to_f32(x.contiguous())
+            x = ops.merge_split(x.contiguous(), 512) if self.precision == "bf16x3" else ops.to_f32(x.contiguous())
         return x
 
 

@@ -48,6 +48,45 @@ def repack_conv_weight(w, dtype):
     return out
 
 
+def split_conv_weight(w):
+    """(Cout, Cin, 3, 3) f32 -> (Cout, 9, 3 Cin) bf16 = [hi | lo | hi] per tap (bf16x3 mode)."""
+    packed = repack_conv_weight(w, torch.float32)
+    cout, _, cin = packed.shape
+    out = torch.empty((cout, 9, 3 * cin), dtype=torch.bfloat16, device=w.device)
+    _lib.check(_lib.lib().mla_split_bf16x3(_p(packed), cout * 9, cin, cin, _p(out), 3 * cin, cin, 3, _lib.stream_ptr()))
+    return out
+
+
+def split_linear_weight(w, seg):
+    """(N, K) f32 -> (N, 3 K) bf16 = [hi | lo | hi] per segment of `seg` input features (bf16x3 mode)."""
+    _chk(w, torch.float32)
+    n, k = w.shape
+    out = torch.empty((n, 3 * k), dtype=torch.bfloat16, device=w.device)
+    _lib.check(_lib.lib().mla_split_bf16x3(_p(w), n, k, k, _p(out), 3 * k, seg, 3, _lib.stream_ptr()))
+    return out
+
+
+def merge_split(x, seg):
+    """(rows, 2 cols) bf16 [hi | lo] per segment -> (rows, cols) f32."""
+    _chk(x, torch.bfloat16)
+    rows, c2 = x.shape
+    out = torch.empty((rows, c2 // 2), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mla_merge_bf16x3(_p(x), rows, c2 // 2, c2, seg, _p(out), _lib.stream_ptr()))
+    return out
+
+
+def linear_split(a, w, b, seg, relu=True, out_split=True):
+    """bf16x3 Linear: a (M, 2K) split activations, w (N, 3K) from split_linear_weight -> (M, 2N) split or (M, N) f32."""
+    _chk(a, torch.bfloat16); _chk(w, torch.bfloat16)
+    M, K = a.shape[0], a.shape[1] // 2
+    N = w.shape[0]
+    assert w.shape[1] == 3 * K
+    out = torch.empty((M, 2 * N), dtype=torch.bfloat16, device=a.device) if out_split else torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _lib.check(_timed("linear_%dx%d" % (K, N), _lib.lib().mla_linear_bf16x3, _p(a), a.stride(0), _p(w), w.stride(0), _p(b), _p(out),
+                      out.stride(0), M, N, K, seg, _lib.BF16X3 if out_split else _lib.F32, int(relu), _lib.stream_ptr()))
+    return out
+
+
 def to_bf16(w):
     _chk(w, torch.float32)
     out = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
@@ -62,13 +101,14 @@ def to_f32(x):
     return out
 
 
-def conv1(x, w, b, dtype):
-    """x (N, 96, 64) f32|bf16 -> (N, 48, 32, 64) NHWC."""
+def conv1(x, w, b, dtype, split=False):
+    """x (N, 96, 64) f32|bf16 -> (N, 48, 32, 64) NHWC; split (bf16x3): f32 in -> (N, 48, 32, 128) = [hi(64) | lo(64)]."""
     _chk(x); _chk(w, torch.float32); _chk(b, torch.float32)
     n = x.shape[0]
     assert tuple(x.shape[1:]) == (96, 64) and tuple(w.shape) == (64, 1, 3, 3)
-    out = torch.empty((n, 48, 32, 64), dtype=dtype, device=x.device)
-    _lib.check(_timed("conv1", _lib.lib().mla_vggish_conv1, _p(x), DT[x.dtype], n, _p(w), _p(b), _p(out), DT[dtype], _lib.stream_ptr()))
+    out = torch.empty((n, 48, 32, 128 if split else 64), dtype=dtype, device=x.device)
+    _lib.check(_timed("conv1", _lib.lib().mla_vggish_conv1, _p(x), DT[x.dtype], n, _p(w), _p(b), _p(out),
+                      _lib.BF16X3 if split else DT[dtype], _lib.stream_ptr()))
     return out
 
 
@@ -76,15 +116,18 @@ CONV_SHAPES = {2: ((48, 32, 64), (24, 16, 128)), 3: ((24, 16, 128), (24, 16, 256
                5: ((12, 8, 256), (12, 8, 512)), 6: ((12, 8, 512), (6, 4, 512))}
 
 
-def conv(layer, x, w_packed, b):
-    """VGGish conv `layer` (2..6) with fused bias + ReLU (+ 2x2 max-pool for 2, 4, 6). NHWC."""
+def conv(layer, x, w_packed, b, split=False):
+    """VGGish conv `layer` (2..6) with fused bias + ReLU (+ 2x2 max-pool for 2, 4, 6). NHWC. split (bf16x3): activations
+    carry [hi | lo] planes (2 C channels), weights [hi | lo | hi] (3 Cin per tap)."""
     _chk(x); _chk(w_packed, x.dtype); _chk(b, torch.float32)
     shp_in, shp_out = CONV_SHAPES[layer]
-    assert tuple(x.shape[1:]) == shp_in, (x.shape, shp_in)
-    assert tuple(w_packed.shape) == (shp_out[2], 9, shp_in[2])
+    ka, kw, ko = (2, 3, 2) if split else (1, 1, 1)
+    assert tuple(x.shape[1:]) == shp_in[:2] + (ka * shp_in[2],), (x.shape, shp_in)
+    assert tuple(w_packed.shape) == (shp_out[2], 9, kw * shp_in[2])
     n = x.shape[0]
-    out = torch.empty((n,) + shp_out, dtype=x.dtype, device=x.device)
-    _lib.check(_timed("conv%d" % layer, _lib.lib().mla_vggish_conv, layer, _p(x), _p(w_packed), _p(b), _p(out), n, DT[x.dtype], _lib.stream_ptr()))
+    out = torch.empty((n,) + shp_out[:2] + (ko * shp_out[2],), dtype=x.dtype, device=x.device)
+    _lib.check(_timed("conv%d" % layer, _lib.lib().mla_vggish_conv, layer, _p(x), _p(w_packed), _p(b), _p(out), n,
+                      _lib.BF16X3 if split else DT[x.dtype], _lib.stream_ptr()))
     return out
 
 

@@ -6,7 +6,8 @@ HIP kernels of libmla_hip.so (csrc/conv.hip, csrc/gemm.hip).
 The modules inside ``features`` / ``embeddings`` only HOLD parameters in the reference's
 layout; the containers run the fused HIP pipeline (conv + bias + ReLU + max-pool in one
 kernel per conv, NHWC activations). Extra keyword ``precision`` ("f32" exact-MFMA parity
-mode, default, or "bf16") is the one addition to the reference signatures.
+mode, default, "bf16", or "bf16x3": f32-grade results from three bf16 MFMA products per term) is the one addition to
+the reference signatures.
 """
 
 import math
@@ -18,7 +19,7 @@ import torch.nn as nn
 from . import vggish_input, vggish_params
 from .. import ops
 
-_DTYPES = {"f32": torch.float32, "bf16": torch.bfloat16}
+_DTYPES = {"f32": torch.float32, "bf16": torch.bfloat16, "bf16x3": torch.bfloat16}     # bf16x3: split planes, see MLA_BF16X3
 
 
 class Conv3x3(nn.Module):
@@ -79,12 +80,20 @@ class VGGFeatures(nn.Sequential):
         self._convs = convs
 
     def forward_nhwc(self, x, dtype):
-        """x: (N, 96, 64) or (N, 1, 96, 64) examples, f32 or bf16 -> (N, 6, 4, 512) NHWC."""
+        """x: (N, 96, 64) or (N, 1, 96, 64) examples, f32 or bf16 -> (N, 6, 4, 512) NHWC
+        (precision "bf16x3": (N, 6, 4, 1024) = [hi(512) | lo(512)] per pixel)."""
         x = x.detach().reshape(-1, 96, 64)
         if x.dtype not in (torch.float32, torch.bfloat16):
             x = x.float()
         x = x.contiguous()
         convs = self._convs
+        if self.precision == "bf16x3":
+            packed = self._cache.get([c.weight for c in convs[1:]], "bf16x3",
+                                     lambda: [ops.split_conv_weight(c.weight.detach().contiguous()) for c in convs[1:]])
+            h = ops.conv1(x.float(), convs[0].weight.detach().contiguous(), convs[0].bias.detach(), torch.bfloat16, split=True)
+            for layer, (c, w) in enumerate(zip(convs[1:], packed), start=2):
+                h = ops.conv(layer, h, w, c.bias.detach(), split=True)
+            return h
         packed = self._cache.get([c.weight for c in convs[1:]], dtype,
                                  lambda: [ops.repack_conv_weight(c.weight.detach().contiguous(), dtype) for c in convs[1:]])
         h = ops.conv1(x, convs[0].weight.detach().contiguous(), convs[0].bias.detach(), dtype)
@@ -126,6 +135,16 @@ class VGGEmbeddings(nn.Sequential):
     def forward(self, x):
         dtype = _DTYPES[self.precision]
         fcs = self._fcs
+        if self.precision == "bf16x3":
+            # the conv stack's flatten is pixel-major with [hi(512) | lo(512)] per pixel; later layers have one plane pair
+            segs = [512, fcs[1].in_features, fcs[2].in_features]
+            ws = self._cache.get([f.weight for f in fcs], "bf16x3",
+                                 lambda: [ops.split_linear_weight(f.weight.detach().contiguous(), sg) for f, sg in zip(fcs, segs)])
+            h = x.detach()
+            assert h.dtype == torch.bfloat16 and h.is_contiguous() and h.shape[1] == 2 * fcs[0].in_features
+            for i, (f, w, sg) in enumerate(zip(fcs, ws, segs)):
+                h = ops.linear_split(h, w, f.bias.detach(), sg, relu=True, out_split=i < len(fcs) - 1)
+            return h
         if dtype == torch.float32:
             ws = [f.weight.detach() for f in fcs]
         else:

@@ -42,6 +42,10 @@ extern "C" {
 #define MLA_F32   0
 #define MLA_BF16  1
 #define MLA_I16   2
+#define MLA_BF16X3 3  /* "split" bf16: x = hi + lo, two bf16 planes [hi(C) | lo(C)] per row / pixel; three bf16 MFMA
+                        * products per term (hi*hi + hi*lo + lo*hi) with f32 accumulation: f32-grade results (2^-18
+                        * relative per product) at a third of the bf16 rate. Accepted by mla_vggish_conv1 (output),
+                        * mla_vggish_conv and mla_linear_bf16x3; weights are prepared by mla_split_bf16x3. */
 
 typedef void* mla_stream_t;            /* hipStream_t */
 
@@ -123,6 +127,19 @@ int mla_conv_repack_weights(const float* w_oihw, int64_t cout, int64_t cin, void
 int mla_convert_f32(const float* in, void* out, int64_t n, int dtype, mla_stream_t stream);
 /* bf16 -> f32 copy (bf16 conv bottlenecks feeding the f32 MLA head, model.py:162-167 path). */
 int mla_convert_bf16_to_f32(const void* in, float* out, int64_t n, mla_stream_t stream);
+/* MLA_BF16X3 operand preparation: float32 (rows, cols) -> bf16 planes per segment of `seg` columns, [hi | lo] (copies = 2:
+ * activations) or [hi | lo | hi] (copies = 3: weights; conv weights: rows = Cout*9 of the (Cout, 9, Cin) repack, seg = Cin;
+ * Linear weights: seg = the activation's plane length, 512 after the conv stack's NHWC flatten, else in_features). */
+int mla_split_bf16x3(const float* in, int64_t rows, int64_t cols, int64_t ld_in, void* out, int64_t ld_out, int64_t seg,
+                     int copies, mla_stream_t stream);
+/* split (rows, 2 cols) = [hi | lo] per segment -> float32 (rows, cols) = hi + lo (the bottleneck features of
+ * just_bottlenecks=True, model.py:162-167, handed to the float32 head). */
+int mla_merge_bf16x3(const void* in, int64_t rows, int64_t cols, int64_t ld_in, int64_t seg, float* out, mla_stream_t stream);
+/* nn.Linear in the MLA_BF16X3 mode (vggish.py:13-19 at f32-grade accuracy on the bf16 matrix cores): a (M, 2K) split
+ * activations, w (N, 3K) from mla_split_bf16x3, K = in_features, seg as above; out_dtype MLA_F32 (M, N) or MLA_BF16X3
+ * (M, 2N) = [hi(N) | lo(N)]. */
+int mla_linear_bf16x3(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* out, int64_t ldo,
+                      int64_t M, int64_t N, int64_t K, int64_t seg, int out_dtype, int relu, mla_stream_t stream);
 
 /* features[0..2]: Conv2d(1, 64, 3, pad 1) + ReLU + MaxPool2d(2, 2) fused.
  * x: (n, 96, 64) examples (x_dtype MLA_F32 | MLA_BF16); w: (64, 1, 3, 3) f32; bias (64) f32;

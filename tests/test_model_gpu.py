@@ -265,3 +265,26 @@ def test_full_size_forward_properties(model, W):
         assert rel_err(out[:2].cpu(), ref.numpy()) < 5e-2
         ens.set_precision("f32")
         assert rel_err(ens.forward_waveforms(pcm[:2]).cpu(), ref.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("jb", [False, True])
+def test_bf16x3_mode_meets_the_f32_tolerance(model, golden, W, jb):
+    """precision="bf16x3": every value travels as hi + lo bf16 planes and every product as three bf16 MFMA terms with f32
+    accumulation. Must meet the north-star tolerance (1e-4 relative on the scores) like the exact-f32 mode."""
+    g = golden("model_ensemble")
+    ens = load(model.Ensemble("repeat", dict(CNN_CONF, just_bottlenecks=jb), [2, 1], torch.device("cuda"), precision="bf16x3"),
+               W.make_state_dict(6, W.ensemble_shapes((2, 1), jb)))
+    ens.eval()
+    ref = g["wave2logits/jb%d" % jb]
+    pcm = torch.from_numpy(W.waveform(21, 160000, 2)).cuda()
+    with torch.no_grad():
+        out = ens.forward_waveforms(pcm)
+        err = rel_err(out.cpu(), ref)
+        print("bf16x3 wave->logits rel err vs f32 reference (jb=%d): %.3g" % (jb, err))
+        assert err < 1e-4
+        # and against the exact-f32 mode of this library, layer output by layer output is covered by the scores; embeddings:
+        if not jb:
+            ex = importlib.import_module(PKG + ".frontend").waveforms_to_examples(pcm)
+            e3 = ens.cnn(ex)
+            e1 = ens.set_precision("f32").cnn(ex)
+            assert rel_err(e3.cpu(), e1.cpu().numpy()) < 2e-5
