@@ -32,7 +32,7 @@ using namespace mma;
 constexpr int kThreads = 512, kWavesN = 4, kMS = 6;
 
 // SPLIT ("bf16x3"): every f32 value x travels as two bf16, hi = bf16(x) and lo = bf16(x - hi) (x = hi + lo to 2^-18
-// relative). Activations hold [hi(C) | lo(C)] per pixel, repacked weights [hi(Cin) | lo(Cin) | hi(Cin)] per tap, and
+// relative). Activations hold [hi(C) | lo(C)] per pixel, repacked weights [hi | lo | hi] per 64-channel chunk and tap, and
 // the K loop runs the three products a_hi w_hi + a_hi w_lo + a_lo w_hi (bf16 products are exact in the f32 accumulator;
 // the dropped a_lo w_lo is 2^-18 relative): f32-grade results at a third of the bf16 MFMA rate.
 template <typename T, int CIN_, int COUT_, int H_, int W_, bool POOL_, int NS_, bool ACT_ = true, bool SPLIT_ = false>
@@ -151,8 +151,9 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
     constexpr int A_PASSES = (A_PIECES + kThreads - 1) / kThreads;
     constexpr int CHUNKS = C::CIN_W / C::KC;                // K chunks per tap (three passes over the input planes when SPLIT)
     constexpr int PLANE = C::CIN / C::KC;                    // chunks per input plane
-    // input channel offset that pairs with weight chunk c: [a_hi | a_hi | a_lo] against [w_hi | w_lo | w_hi]
-    auto a_chan = [](int c) { return (!C::SPLIT || c < 2 * PLANE ? c % PLANE : c - PLANE) * C::KC; };
+    // input channel offset that pairs with weight chunk c. SPLIT: the weights hold [w_hi | w_lo | w_hi] per 64-channel
+    // chunk k, paired with [a_hi_k | a_hi_k | a_lo_k]: the hi patch staged for pass 0 is reused by pass 1
+    auto a_chan = [](int c) { return (!C::SPLIT ? c : (c % 3 < 2 ? c / 3 : PLANE + c / 3)) * C::KC; };
 
     // Global operands through buffer descriptors (wave-uniform base, 32-bit per-lane offsets fixed
     // for the whole kernel, scalar offset per tap / chunk). Out-of-image halo pixels and images past
@@ -230,12 +231,13 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
             const int c0 = c * C::KC;
             const bool last_chunk = c + 1 == CHUNKS;
             const bool more = !last_chunk || has_next;                       // another stage follows
+            const bool new_patch = more && !(C::SPLIT && !last_chunk && c % 3 == 0);   // the next stage needs other input channels
             _Pragma("unroll") for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap % 3;
                 const int cur = par ? C::B_BYTES : 0;
                 if (tap < 8) b_load(c0, tap + 1);
                 else if (more) b_load(last_chunk ? 0 : c0 + C::KC, 0);
-                if (tap == 5 && more) {
+                if (tap == 5 && new_patch) {
                     if (last_chunk) a_rsrc = patch_rsrc((next_tile / C::TILES_Y) * C::IMGS);
                     a_load(last_chunk ? 0 : a_chan(c + 1));
                 }
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                 }
                 if (tap < 8 || more) b_write(cur ^ C::B_BYTES);
                 __syncthreads();
-                if (tap == 8 && more) {          // every wave has finished reading the old patch
+                if (tap == 8 && new_patch) {     // every wave has finished reading the old patch
                     a_write();
                     __syncthreads();
                 }

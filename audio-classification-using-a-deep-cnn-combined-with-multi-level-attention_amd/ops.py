@@ -49,11 +49,11 @@ def repack_conv_weight(w, dtype):
 
 
 def split_conv_weight(w):
-    """(Cout, Cin, 3, 3) f32 -> (Cout, 9, 3 Cin) bf16 = [hi | lo | hi] per tap (bf16x3 mode)."""
+    """(Cout, Cin, 3, 3) f32 -> (Cout, 9, 3 Cin) bf16 = [hi | lo | hi] per 64-channel chunk and tap (bf16x3 mode)."""
     packed = repack_conv_weight(w, torch.float32)
     cout, _, cin = packed.shape
     out = torch.empty((cout, 9, 3 * cin), dtype=torch.bfloat16, device=w.device)
-    _lib.check(_lib.lib().mla_split_bf16x3(_p(packed), cout * 9, cin, cin, _p(out), 3 * cin, cin, 3, _lib.stream_ptr()))
+    _lib.check(_lib.lib().mla_split_bf16x3(_p(packed), cout * 9, cin, cin, _p(out), 3 * cin, 64, 3, _lib.stream_ptr()))
     return out
 
 

@@ -128,7 +128,7 @@ int mla_convert_f32(const float* in, void* out, int64_t n, int dtype, mla_stream
 /* bf16 -> f32 copy (bf16 conv bottlenecks feeding the f32 MLA head, model.py:162-167 path). */
 int mla_convert_bf16_to_f32(const void* in, float* out, int64_t n, mla_stream_t stream);
 /* MLA_BF16X3 operand preparation: float32 (rows, cols) -> bf16 planes per segment of `seg` columns, [hi | lo] (copies = 2:
- * activations) or [hi | lo | hi] (copies = 3: weights; conv weights: rows = Cout*9 of the (Cout, 9, Cin) repack, seg = Cin;
+ * activations) or [hi | lo | hi] (copies = 3: weights; conv weights: rows = Cout*9 of the (Cout, 9, Cin) repack, seg = 64 = one K chunk;
  * Linear weights: seg = the activation's plane length, 512 after the conv stack's NHWC flatten, else in_features). */
 int mla_split_bf16x3(const float* in, int64_t rows, int64_t cols, int64_t ld_in, void* out, int64_t ld_out, int64_t seg,
                      int copies, mla_stream_t stream);
