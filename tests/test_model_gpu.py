@@ -288,3 +288,29 @@ def test_bf16x3_mode_meets_the_f32_tolerance(model, golden, W, jb):
             e3 = ens.cnn(ex)
             e1 = ens.set_precision("f32").cnn(ex)
             assert rel_err(e3.cpu(), e1.cpu().numpy()) < 2e-5
+
+
+def test_bf16x3_operand_split_and_linear(ops, W):
+    """mla_split_bf16x3 / mla_merge_bf16x3 / mla_linear_bf16x3: x = hi + lo to 2^-17 relative, planes laid out per segment,
+    and the three-product GEMM agrees with the exact-f32 GEMM to f32-grade accuracy."""
+    M, N, K, seg = 200, 192, 1024, 512
+    a = torch.from_numpy(W.uniform(61, 1, M * K, lo=-1.0, hi=3.0)).reshape(M, K).cuda().clamp_min(0)
+    w = torch.from_numpy(W.uniform(61, 2, N * K, lo=-0.05, hi=0.05)).reshape(N, K).cuda()
+    b = torch.from_numpy(W.uniform(61, 3, N, lo=-0.1, hi=0.1)).cuda()
+    # activations: [hi | lo] per segment; weights: [hi | lo | hi]
+    a2 = torch.empty((M, 2 * K), dtype=torch.bfloat16, device="cuda")
+    import ctypes
+    L = importlib.import_module(PKG + "._lib")
+    vp = ctypes.c_void_p
+    L.check(L.lib().mla_split_bf16x3(vp(a.data_ptr()), M, K, K, vp(a2.data_ptr()), 2 * K, seg, 2, L.stream_ptr()))
+    back = ops.merge_split(a2, seg)
+    assert float((back - a).abs().max()) <= 2.0 ** -16 * float(a.abs().max())
+    hi = a2.view(M, K // seg, 2, seg)[:, :, 0, :].float().reshape(M, K)
+    assert torch.equal(hi, a.to(torch.bfloat16).float())                     # hi plane = round-to-nearest bf16 of x
+    w3 = ops.split_linear_weight(w, seg)
+    assert w3.shape == (N, 3 * K) and torch.equal(w3.view(N, K // seg, 3, seg)[:, :, 0, :], w3.view(N, K // seg, 3, seg)[:, :, 2, :])
+    ref = ops.linear(a, w, b, relu=True)                                      # exact-f32 MFMA
+    got = ops.linear_split(a2, w3, b, seg, relu=True, out_split=False)
+    assert rel_err(got.cpu(), ref.cpu().numpy()) < 2e-5
+    got2 = ops.merge_split(ops.linear_split(a2, w3, b, seg, relu=True, out_split=True), N)
+    assert rel_err(got2.cpu(), ref.cpu().numpy()) < 2e-5
