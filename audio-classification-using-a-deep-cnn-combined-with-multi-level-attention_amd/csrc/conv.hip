@@ -55,11 +55,12 @@ struct Cfg {
     static constexpr int KC = Elem<T>::kPerRow;             // channels per 128-byte chunk
     static constexpr int A_BYTES = IMGS * PH * PW * kRowBytes;
     static constexpr int B_BYTES = BN * kRowBytes;
-    static constexpr int LDS_BYTES = A_BYTES + 2 * B_BYTES;
     static constexpr int TILES_Y = H / TH;
     static constexpr bool PERSIST = NS > 2 || SPLIT;        // conv2 (half-width tile): two non-persistent workgroups per CU
                                                             // (its split form has a 3x longer K loop and more epilogue registers)
     static constexpr int MIN_WAVES = (PERSIST || sizeof(T) == 4) ? 2 : 4;      // waves per SIMD the register budget is held to
+    static constexpr int B_BUFS = PERSIST ? 3 : 2;          // weight slices in LDS: three let the LDS-DMA of slice g+2 span a barrier
+    static constexpr int LDS_BYTES = A_BYTES + B_BUFS * B_BYTES;
     static constexpr int HO = POOL ? H / 2 : H, WO = POOL ? W / 2 : W;
     static_assert(W == 32 || W == 16 || W == 8, "tile mapping covers the VGGish widths");
     static_assert(H % TH == 0 && CIN % KC == 0 && COUT % BN == 0, "shape must tile exactly");
@@ -193,31 +194,27 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                 lds_write16(sA, ((im * C::PH + yh) * C::PW + xh) * kRowBytes + 16 * (ch ^ a_swizzle<C>(xh, im)), apre[p]);
         }
     };
-    u32x4 breg[C::NS];
-    auto b_load = [&](int c0, int tap) {   // one (tap, chunk) weight slice: BN rows x 128 B
+    // One (tap, chunk) weight slice (BN rows x 128 B) goes global -> LDS by LDS-DMA (buffer_load ... lds): no staging
+    // registers, no ds_write pass. A wave-instruction fills 1 KiB = 8 consecutive tile rows in lane order, so the
+    // tile's XOR swizzle is applied on the SOURCE side: the lane at (row, slot c') fetches chunk c' ^ swz(row).
+    // LDS row j*16 + r of a wave's NS*16-row block holds output channel r*NS + j of that block: the NS accumulators
+    // of a lane are then NS consecutive channels and leave as one vector store per pixel.
+    auto b_dma = [&](int c0, int tap, int buf_off) {
         _Pragma("unroll") for (int p = 0; p < C::NS; ++p) {
-            // LDS row j*16 + r of a wave's NS*16-row block holds output channel r*NS + j of that block: the NS
-            // accumulators of a lane are then NS consecutive channels and leave as one vector store per pixel
-            // (piece p of a thread is LDS row (t >> 3) + 64 p: the permutation only touches the thread's part)
-            const int row0 = t >> 3, ch = t & 7;
-            const int n = 64 * p + (row0 & (64 - C::NS * 16) & 63) + (row0 & 15) * C::NS + ((row0 >> 4) & (C::NS - 1));
-            breg[p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, int((n * 9 * C::CIN_W + ch * PER) * ESZ),
-                                                            int((tap * C::CIN_W + c0) * ESZ), 0);
-        }
-    };
-    auto b_write = [&](int buf_off) {
-        _Pragma("unroll") for (int p = 0; p < C::NS; ++p) {
-            const int piece = t + kThreads * p;
-            lds_write16(sB, buf_off + tile_off(piece >> 3, piece & 7), breg[p]);
+            const int row = 8 * (wave + 8 * p) + (lane >> 3), slot = lane & 7;
+            const int chunk = slot ^ (((row >> 1) & 3) << 1);                    // inverse of tile_off's swizzle (an involution)
+            const int n = (row & ~(C::NS * 16 - 1)) + (row & 15) * C::NS + ((row >> 4) & (C::NS - 1));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(sB + buf_off + 8 * (wave + 8 * p) * kRowBytes),
+                                                 16, int((n * 9 * C::CIN_W + chunk * PER) * ESZ), int((tap * C::CIN_W + c0) * ESZ), 0, 0);
         }
     };
 
     // prologue: first patch and first weight slice
     a_load(0);
-    b_load(0, 0);
+    b_dma(0, 0, 0);
+    if (C::B_BUFS == 3) b_dma(0, 1, C::B_BYTES);
     a_write();
-    b_write(0);
-    __syncthreads();
+    __syncthreads();                               // (drains the DMA: hipcc waits vmcnt(0) in front of the barrier)
 
     // One barrier per tap. The weight pipeline runs continuously across channel chunks AND across
     // tiles (slice g+1 is fetched before the MFMAs of slice g and parked in the other LDS buffer
@@ -234,9 +231,19 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
             const bool new_patch = more && !(C::SPLIT && !last_chunk && c % 3 == 0);   // the next stage needs other input channels
             _Pragma("unroll") for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap % 3;
-                const int cur = par ? C::B_BYTES : 0;
-                if (tap < 8) b_load(c0, tap + 1);
-                else if (more) b_load(last_chunk ? 0 : c0 + C::KC, 0);
+                const int cur = C::B_BUFS == 3 ? (tap % 3) * C::B_BYTES : (par ? C::B_BYTES : 0);    // 9 taps: stage g lives in g % 3
+                // Weight slices ahead of the MFMAs by LDS-DMA. Two buffers: slice g+1 into the other buffer (its last
+                // readers passed the barrier that ended the previous tap), drained before this tap's barrier. Three
+                // buffers: slice g+2, which may stay in flight across this tap's barrier (counted vmcnt below).
+                bool issued = true;
+                if (C::B_BUFS == 3) {
+                    if (tap < 7) b_dma(c0, tap + 2, ((tap + 2) % 3) * C::B_BYTES);
+                    else if (more) b_dma(last_chunk ? 0 : c0 + C::KC, tap - 7, ((tap + 2) % 3) * C::B_BYTES);
+                    else issued = false;
+                } else {
+                    if (tap < 8) b_dma(c0, tap + 1, cur ^ C::B_BYTES);
+                    else if (more) b_dma(last_chunk ? 0 : c0 + C::KC, 0, cur ^ C::B_BYTES);
+                }
                 if (tap == 5 && new_patch) {
                     if (last_chunk) a_rsrc = patch_rsrc((next_tile / C::TILES_Y) * C::IMGS);
                     a_load(last_chunk ? 0 : a_chan(c + 1));
@@ -256,8 +263,17 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                         _Pragma("unroll") for (int j = 0; j < C::NS; ++j) mma_step<T>(af[i], bf[j], acc[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (tap < 8 || more) b_write(cur ^ C::B_BYTES);
-                __syncthreads();
+                if (C::B_BUFS == 3) {
+                    // slice g+1 (issued one tap ago) must have landed; younger operations may stay in flight: this tap's
+                    // slice g+2 (NS per wave) and, around tap 5, the patch prefetch (A_PASSES register loads)
+                    const bool patch_in_flight = new_patch && (tap == 5 || tap == 6);
+                    if (patch_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NS + A_PASSES) : "memory");
+                    else if (issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NS) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();      // raw: __syncthreads() would drain the DMA in flight
+                } else {
+                    __syncthreads();               // DMA landed (vmcnt(0) precedes the barrier) and every wave is done with `cur`
+                }
                 if (tap == 8 && new_patch) {     // every wave has finished reading the old patch
                     a_write();
                     __syncthreads();

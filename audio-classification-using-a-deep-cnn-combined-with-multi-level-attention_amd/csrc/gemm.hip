@@ -17,7 +17,11 @@ using namespace mma;
 
 constexpr int kThreads = 512;
 
-template <typename T, typename TO, int MS, int NS, bool RELU>
+// DMA: both operand tiles go global -> LDS by LDS-DMA (buffer_load ... lds, 1 KiB = 8 tile rows per wave-instruction, the
+// tile's XOR swizzle applied on the source side) instead of through registers + ds_write: no staging registers, no
+// write pass in front of the barrier. Needs K % (64 or 32) == 0: an out-of-range DMA lane is dropped, not zero-filled
+// (rows past M / N only feed masked outputs; a K tail would feed valid ones).
+template <typename T, typename TO, int MS, int NS, bool RELU, bool DMA = false>
 __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__ A, int64_t lda,
                                                             const T* __restrict__ W, int64_t ldw,
                                                             const float* __restrict__ bias, TO* __restrict__ out,
@@ -75,17 +79,51 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
         }
     };
 
+    constexpr uint32_t ESZ = sizeof(T);
+    const int a_rows = M - m0 < kBM ? M - m0 : kBM, w_rows = N - n0 < BN ? N - n0 : BN;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(A) + size_t(m0) * lda, 0,
+                                                                          uint32_t(a_rows) * uint32_t(lda) * ESZ, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(W) + size_t(n0) * ldw, 0,
+                                                                          uint32_t(w_rows) * uint32_t(ldw) * ESZ, 0x00020000);
+    auto dma = [&](int s, int buf) {
+        int sa = s;
+        if (seg) {
+            const int blk = s / (3 * seg), rr = s - blk * 3 * seg;
+            sa = blk * 2 * seg + (rr < seg ? rr : rr - seg);
+        }
+        const int slot = lane & 7;
+        _Pragma("unroll") for (int p = 0; p < kBM / 64; ++p) {
+            const int row = 8 * (wave + 8 * p) + (lane >> 3);
+            const int chunk = slot ^ (((row >> 1) & 3) << 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(sA + buf * A_BYTES + 8 * (wave + 8 * p) * kRowBytes),
+                                                     16, int((uint32_t(row) * uint32_t(lda) + chunk * PER) * ESZ), int(sa * KC * ESZ), 0, 0);
+        }
+        _Pragma("unroll") for (int p = 0; p < BN / 64; ++p) {
+            const int row = 8 * (wave + 8 * p) + (lane >> 3);
+            const int chunk = slot ^ (((row >> 1) & 3) << 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(sB + buf * B_BYTES + 8 * (wave + 8 * p) * kRowBytes),
+                                                     16, int((uint32_t(row) * uint32_t(ldw) + chunk * PER) * ESZ), int(s * KC * ESZ), 0, 0);
+        }
+    };
+
     // split-K: blockIdx.z owns a contiguous range of K stages and writes raw partial sums
     const int all_stages = (K + KC - 1) / KC;
     const int per_split = (all_stages + int(gridDim.z) - 1) / int(gridDim.z);
     const int s_begin = int(blockIdx.z) * per_split;
     const int stages = (s_begin + per_split < all_stages ? s_begin + per_split : all_stages);
-    gload(s_begin);
-    lwrite(s_begin & 1);
+    if (DMA) {
+        dma(s_begin, s_begin & 1);
+    } else {
+        gload(s_begin);
+        lwrite(s_begin & 1);
+    }
     __syncthreads();
     for (int s = s_begin; s < stages; ++s) {
         const int buf = s & 1;
-        if (s + 1 < stages) gload(s + 1);
+        if (s + 1 < stages) {
+            if (DMA) dma(s + 1, buf ^ 1);      // the other buffer's last readers passed the barrier that ended stage s - 1
+            else gload(s + 1);
+        }
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {
             u32x4 af[kMS], bf[NS];
             _Pragma("unroll") for (int i = 0; i < kMS; ++i)
@@ -97,8 +135,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
                 _Pragma("unroll") for (int j = 0; j < NS; ++j) mma_step<T>(af[i], bf[j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (s + 1 < stages) lwrite(buf ^ 1);   // the other buffer was last read before the previous barrier
-        __syncthreads();
+        if (!DMA && s + 1 < stages) lwrite(buf ^ 1);   // the other buffer was last read before the previous barrier
+        __syncthreads();                               // (with a DMA in flight hipcc waits vmcnt(0) in front of the barrier)
     }
 
     if (partial) {                          // raw sums of this K range; bias / activation happen in the reduction
@@ -160,7 +198,11 @@ int launch(const void* a, int64_t lda, const void* w, int64_t ldw, const float* 
            int64_t M, int64_t N, int64_t K, hipStream_t s, int splits = 1, float* partial = nullptr, int seg = 0, int osplit = 0) {
     constexpr int kBM = 2 * MS * 16, BN = 4 * NS * 16;
     constexpr int lds = 2 * (kBM + BN) * kRowBytes;
-    auto kern = gemm_kernel<T, TO, MS, NS, RELU>;
+    // LDS-DMA staging when no K tail needs zero filling and the descriptors' 32-bit byte ranges suffice
+    constexpr int KCE = mma::Elem<T>::kPerRow;
+    const bool use_dma = K % KCE == 0 && uint64_t(kBM) * uint64_t(lda) * sizeof(T) < (1ull << 31) &&
+                         uint64_t(BN) * uint64_t(ldw) * sizeof(T) < (1ull << 31);
+    auto kern = use_dma ? gemm_kernel<T, TO, MS, NS, RELU, true> : gemm_kernel<T, TO, MS, NS, RELU, false>;
     MLA_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const dim3 grid{unsigned((M + kBM - 1) / kBM), unsigned((N + BN - 1) / BN), unsigned(splits)};
     hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, static_cast<const T*>(a), lda, static_cast<const T*>(w), ldw,
