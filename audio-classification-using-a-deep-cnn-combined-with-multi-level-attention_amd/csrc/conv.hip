@@ -53,14 +53,17 @@ struct Cfg {
     static constexpr int PW = W + 2, PH = TH + 2;           // patch with halo
     static constexpr int BN = kWavesN * NS * 16;
     static constexpr int KC = Elem<T>::kPerRow;             // channels per 128-byte chunk
-    static constexpr int A_BYTES = IMGS * PH * PW * kRowBytes;
+    static constexpr int A_PIX = IMGS * PH * PW;            // patch pixels (one 128-byte row each)
+    static constexpr int A_BYTES = (A_PIX + 7) / 8 * 8 * kRowBytes;   // padded to whole 1 KiB LDS-DMA pieces
     static constexpr int B_BYTES = BN * kRowBytes;
     static constexpr int TILES_Y = H / TH;
     static constexpr bool PERSIST = NS > 2 || SPLIT;        // conv2 (half-width tile): two non-persistent workgroups per CU
                                                             // (its split form has a 3x longer K loop and more epilogue registers)
     static constexpr int MIN_WAVES = (PERSIST || sizeof(T) == 4) ? 2 : 4;      // waves per SIMD the register budget is held to
-    static constexpr int B_BUFS = PERSIST ? 3 : 2;          // weight slices in LDS: three let the LDS-DMA of slice g+2 span a barrier
-    static constexpr int LDS_BYTES = A_BYTES + B_BUFS * B_BYTES;
+    static constexpr bool A_DMA = PERSIST;                  // input patches by LDS-DMA into two alternating buffers (else: one
+                                                            // buffer, register-staged -- the two-workgroups-per-CU configurations)
+    static constexpr int A_BUFS = A_DMA ? 2 : 1;
+    static constexpr int LDS_BYTES = A_BUFS * A_BYTES + 2 * B_BYTES;
     static constexpr int HO = POOL ? H / 2 : H, WO = POOL ? W / 2 : W;
     static_assert(W == 32 || W == 16 || W == 8, "tile mapping covers the VGGish widths");
     static_assert(H % TH == 0 && CIN % KC == 0 && COUT % BN == 0, "shape must tile exactly");
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
     constexpr int PER = Elem<T>::kPerChunk;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
-    char* sB = smem + C::A_BYTES;
+    char* sB = smem + C::A_BUFS * C::A_BYTES;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 2, wn = wave & 3;
     const int r = lane & 15, q = lane >> 4;
@@ -209,17 +212,46 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
         }
     };
 
+    // Input patch of one channel chunk by LDS-DMA (A_DMA): eight patch pixels per wave-instruction, swizzle on the
+    // source side. Out-of-image halo pixels (and images past the batch) carry an out-of-range offset: the range check
+    // DROPS those lanes, so the halo rows of both patch buffers are zeroed once, below, and never written again -- they
+    // are the same LDS rows for every tile of this workgroup (its tile row is fixed, the x halo always is).
+    auto a_dma = [&](int c0, int abuf) {
+        constexpr int A_INSTRS = (C::A_PIX + 7) / 8;
+        _Pragma("unroll") for (int p = 0; p < (A_INSTRS + 7) / 8; ++p) {
+            const int wi = wave + 8 * p;                           // wave-uniform piece index
+            if (wi < A_INSTRS) {
+                const int pix = 8 * wi + (lane >> 3), slot = lane & 7;
+                const int xh = pix % C::PW, rest = pix / C::PW;
+                const int yh = rest % C::PH, im = rest / C::PH;
+                const int gy = y_tile + yh - 1, gx = xh - 1;
+                const bool ok = pix < C::A_PIX && gy >= 0 && gy < C::H && gx >= 0 && gx < C::W;
+                const int chunk = slot ^ a_swizzle<C>(xh, im);
+                const int voff = ok ? int((((im * C::H + gy) * C::W + gx) * C::CIN_A + chunk * PER) * ESZ) : int(0x7fffff00);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(sA + abuf * C::A_BYTES + wi * 8 * kRowBytes),
+                                                         16, voff, int(c0 * ESZ), 0, 0);
+            }
+        }
+    };
+
     // prologue: first patch and first weight slice
-    a_load(0);
-    b_dma(0, 0, 0);
-    if (C::B_BUFS == 3) b_dma(0, 1, C::B_BYTES);
-    a_write();
+    int abuf = 0;
+    if constexpr (C::A_DMA) {
+        for (int i = t; i < C::A_BUFS * C::A_BYTES / 16; i += kThreads) lds_write16(sA, 16 * i, zero16());
+        __syncthreads();                           // zeros are in place before any DMA can land
+        a_dma(0, 0);
+        b_dma(0, 0, 0);
+    } else {
+        a_load(0);
+        b_dma(0, 0, 0);
+        a_write();
+    }
     __syncthreads();                               // (drains the DMA: hipcc waits vmcnt(0) in front of the barrier)
 
-    // One barrier per tap. The weight pipeline runs continuously across channel chunks AND across
-    // tiles (slice g+1 is fetched before the MFMAs of slice g and parked in the other LDS buffer
-    // after them); the next chunk's / next tile's input patch is fetched during taps 5..8 and
-    // swapped in behind one extra barrier, so no global round trip is exposed at a boundary.
+    // One barrier per tap. The weight pipeline runs continuously across channel chunks AND across tiles (slice g+1 is
+    // DMA'd into the other LDS buffer under the MFMAs of slice g); the next chunk's / next tile's input patch is DMA'd
+    // into the other patch buffer early in the current chunk (register-staged and swapped in behind one extra barrier
+    // where only one patch buffer fits), so no global round trip is exposed at a boundary.
     int par = 0;                                   // parity of the running tap counter -> current weight buffer
     for (;;) {
         const int next_tile = tile + int(gridDim.x);
@@ -231,27 +263,25 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
             const bool new_patch = more && !(C::SPLIT && !last_chunk && c % 3 == 0);   // the next stage needs other input channels
             _Pragma("unroll") for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap % 3;
-                const int cur = C::B_BUFS == 3 ? (tap % 3) * C::B_BYTES : (par ? C::B_BYTES : 0);    // 9 taps: stage g lives in g % 3
-                // Weight slices ahead of the MFMAs by LDS-DMA. Two buffers: slice g+1 into the other buffer (its last
-                // readers passed the barrier that ended the previous tap), drained before this tap's barrier. Three
-                // buffers: slice g+2, which may stay in flight across this tap's barrier (counted vmcnt below).
-                bool issued = true;
-                if (C::B_BUFS == 3) {
-                    if (tap < 7) b_dma(c0, tap + 2, ((tap + 2) % 3) * C::B_BYTES);
-                    else if (more) b_dma(last_chunk ? 0 : c0 + C::KC, tap - 7, ((tap + 2) % 3) * C::B_BYTES);
-                    else issued = false;
+                const int cur = par ? C::B_BYTES : 0;
+                // next weight slice into the other buffer (its last readers passed the barrier that ended the previous tap)
+                if (tap < 8) b_dma(c0, tap + 1, cur ^ C::B_BYTES);
+                else if (more) b_dma(last_chunk ? 0 : c0 + C::KC, 0, cur ^ C::B_BYTES);
+                if constexpr (C::A_DMA) {
+                    if (tap == 2 && new_patch) {   // next chunk's / tile's patch into the other patch buffer (idle since the previous chunk)
+                        if (last_chunk) a_rsrc = patch_rsrc((next_tile / C::TILES_Y) * C::IMGS);
+                        a_dma(last_chunk ? 0 : a_chan(c + 1), abuf ^ 1);
+                    }
                 } else {
-                    if (tap < 8) b_dma(c0, tap + 1, cur ^ C::B_BYTES);
-                    else if (more) b_dma(last_chunk ? 0 : c0 + C::KC, 0, cur ^ C::B_BYTES);
-                }
-                if (tap == 5 && new_patch) {
-                    if (last_chunk) a_rsrc = patch_rsrc((next_tile / C::TILES_Y) * C::IMGS);
-                    a_load(last_chunk ? 0 : a_chan(c + 1));
+                    if (tap == 5 && new_patch) {
+                        if (last_chunk) a_rsrc = patch_rsrc((next_tile / C::TILES_Y) * C::IMGS);
+                        a_load(last_chunk ? 0 : a_chan(c + 1));
+                    }
                 }
                 _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {
                     u32x4 af[kMS], bf[C::NS];
                     _Pragma("unroll") for (int i = 0; i < kMS; ++i)
-                        af[i] = lds_read16(sA, (abase[kx] ^ (ks << 6)) + (i + ky) * C::PW * kRowBytes);
+                        af[i] = lds_read16(sA + abuf * C::A_BYTES, (abase[kx] ^ (ks << 6)) + (i + ky) * C::PW * kRowBytes);
                     _Pragma("unroll") for (int j = 0; j < C::NS; ++j)
                         bf[j] = lds_read16(sB, cur + (bbase ^ (ks << 6)) + j * 16 * kRowBytes);
                     // Coarse phases: every fragment read of the k-step is issued before the first MFMA and
@@ -263,20 +293,14 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                         _Pragma("unroll") for (int j = 0; j < C::NS; ++j) mma_step<T>(af[i], bf[j], acc[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (C::B_BUFS == 3) {
-                    // slice g+1 (issued one tap ago) must have landed; younger operations may stay in flight: this tap's
-                    // slice g+2 (NS per wave) and, around tap 5, the patch prefetch (A_PASSES register loads)
-                    const bool patch_in_flight = new_patch && (tap == 5 || tap == 6);
-                    if (patch_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NS + A_PASSES) : "memory");
-                    else if (issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NS) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();      // raw: __syncthreads() would drain the DMA in flight
+                __syncthreads();                   // DMA landed (vmcnt(0) precedes the barrier) and every wave is done with `cur`
+                if constexpr (C::A_DMA) {
+                    if (tap == 8 && new_patch) abuf ^= 1;
                 } else {
-                    __syncthreads();               // DMA landed (vmcnt(0) precedes the barrier) and every wave is done with `cur`
-                }
-                if (tap == 8 && new_patch) {     // every wave has finished reading the old patch
-                    a_write();
-                    __syncthreads();
+                    if (tap == 8 && new_patch) { // every wave has finished reading the old patch
+                        a_write();
+                        __syncthreads();
+                    }
                 }
                 par ^= 1;
             }
