@@ -81,10 +81,10 @@ template <> __device__ __forceinline__ void store_vec<float, 2>(float* p, const 
     *reinterpret_cast<f32x2*>(p) = f32x2{v[0], v[1]};
 }
 template <> __device__ __forceinline__ void store_vec<bf16_t, 4>(bf16_t* p, const float* v) {
-    *reinterpret_cast<u32x2*>(p) = u32x2{uint32_t(f2bf(v[0])) | (uint32_t(f2bf(v[1])) << 16), uint32_t(f2bf(v[2])) | (uint32_t(f2bf(v[3])) << 16)};
+    *reinterpret_cast<u32x2*>(p) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
 }
 template <> __device__ __forceinline__ void store_vec<bf16_t, 2>(bf16_t* p, const float* v) {
-    *reinterpret_cast<uint32_t*>(p) = uint32_t(f2bf(v[0])) | (uint32_t(f2bf(v[1])) << 16);
+    *reinterpret_cast<uint32_t*>(p) = pack_bf16x2(v[0], v[1]);
 }
 
 template <> __device__ __forceinline__ void store_vec<float, 1>(float* p, const float* v) { *p = v[0]; }

@@ -46,6 +46,12 @@ __device__ __forceinline__ uint16_t f2bf(float f) {     // round-to-nearest-even
     return __builtin_bit_cast(uint16_t, h);
 }
 __device__ __forceinline__ float bf2f(uint16_t b) { return __builtin_bit_cast(float, uint32_t(b) << 16); }
+// two floats -> one dword of bf16 (lo | hi << 16): ONE v_cvt_pk_bf16_f32 (converting singly costs a cvt each plus a shift/or pair)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
 
 template <typename T> __device__ __forceinline__ void store_elem(T* p, float v);
 template <> __device__ __forceinline__ void store_elem<float>(float* p, float v) { *p = v; }
