@@ -147,9 +147,15 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
     }
     const int bbase = tile_off(wn * C::NS * 16 + r, q);
 
+    // The accumulators start at the bias (a lane's four values of a subtile share its channel), so the epilogue is a
+    // bare ReLU (+ pool): one VALU pass less per tile. The lane's NS accumulators of a pixel are NS consecutive channels
+    // (see b_dma).
+    const int nb = n0 + (wn * 16 + r) * C::NS;
+    float bv[C::NS];
+    _Pragma("unroll") for (int j = 0; j < C::NS; ++j) bv[j] = C::ACT ? bias[nb + j] : 0.f;
     f32x4 acc[kMS][C::NS];
     _Pragma("unroll") for (int i = 0; i < kMS; ++i)
-        _Pragma("unroll") for (int j = 0; j < C::NS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        _Pragma("unroll") for (int j = 0; j < C::NS; ++j) acc[i][j] = f32x4{bv[j], bv[j], bv[j], bv[j]};
 
     constexpr int A_PIECES = C::IMGS * C::PH * C::PW * 8;
     constexpr int A_PASSES = (A_PIECES + kThreads - 1) / kThreads;
@@ -306,19 +312,16 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
             }
         }
 
-        // epilogue: bias + ReLU (+ lane-local 2x2 max-pool; max commutes with the monotone bias+ReLU). The lane's NS
-        // accumulators of a pixel are NS consecutive channels (see b_load): one vector store per pixel.
+        // epilogue: ReLU (+ lane-local 2x2 max-pool; max commutes with the monotone ReLU; the bias is already in the
+        // accumulators); one vector store per pixel.
         {
-            const int nb = n0 + (wn * 16 + r) * C::NS;
-            float bv[C::NS];
-            _Pragma("unroll") for (int j = 0; j < C::NS; ++j) bv[j] = bias[nb + j];
             if (C::POOL) {
                 _Pragma("unroll") for (int ip = 0; ip < kMS / 2; ++ip) {
                     float p0[C::NS], p1[C::NS];
                     _Pragma("unroll") for (int j = 0; j < C::NS; ++j) {
                         const f32x4 u = acc[2 * ip][j], d = acc[2 * ip + 1][j];
-                        p0[j] = fmaxf(fmaxf(fmaxf(u.x, u.y), fmaxf(d.x, d.y)) + bv[j], 0.f);
-                        p1[j] = fmaxf(fmaxf(fmaxf(u.z, u.w), fmaxf(d.z, d.w)) + bv[j], 0.f);
+                        p0[j] = fmaxf(fmaxf(fmaxf(u.x, u.y), fmaxf(d.x, d.y)), 0.f);
+                        p1[j] = fmaxf(fmaxf(fmaxf(u.z, u.w), fmaxf(d.z, d.w)), 0.f);
                     }
                     const int yo = (y_tile + l_y0 + 2 * ip) >> 1;
                     const int img = img0 + (C::SEGW == 8 ? (q >> 1) : 0);
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                     const int y = y_tile + l_y0 + i;
                     _Pragma("unroll") for (int e = 0; e < 4; ++e) {
                         float v[C::NS];
-                        _Pragma("unroll") for (int j = 0; j < C::NS; ++j) v[j] = C::ACT ? fmaxf(acc[i][j][e] + bv[j], 0.f) : acc[i][j][e];
+                        _Pragma("unroll") for (int j = 0; j < C::NS; ++j) v[j] = C::ACT ? fmaxf(acc[i][j][e], 0.f) : acc[i][j][e];
                         const int rr = 4 * q + e;
                         const int img = img0 + (C::SEGW == 8 ? (rr >> 3) : 0);
                         const int x = C::SEGW == 8 ? (rr & 7) : ((C::SEGS == 2 ? wm * 16 : 0) + rr);
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
         tile = next_tile;
         img0 = (tile / C::TILES_Y) * C::IMGS;
         _Pragma("unroll") for (int i = 0; i < kMS; ++i)
-            _Pragma("unroll") for (int j = 0; j < C::NS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            _Pragma("unroll") for (int j = 0; j < C::NS; ++j) acc[i][j] = f32x4{bv[j], bv[j], bv[j], bv[j]};
     }
 }
 
