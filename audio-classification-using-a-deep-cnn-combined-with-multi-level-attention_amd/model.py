@@ -96,6 +96,35 @@ class Ensemble(nn.Module):
         features = self.cnn(ex)
         return self.mla(features.reshape(-1, T, self.emb_input_size))
 
+    def stream_waveforms(self, host_batches):
+        """Host-resident PCM: iterate over (B, n_samples) float32 / int16 tensors in PINNED host memory and yield the
+        (B, K) scores of each. The copy of batch i+1 runs on its own HIP stream while batch i computes (two device
+        buffers), so a steady stream is bound by max(copy, compute), not their sum. Scores are yielded after the batch's
+        compute has been enqueued; they are ordinary tensors on the current stream."""
+        dev = next(self.parameters()).device
+        cur = torch.cuda.current_stream(dev)
+        copy = torch.cuda.Stream(device=dev)
+        it = iter(host_batches)
+
+        def upload(host):
+            assert host.is_pinned(), "stream_waveforms overlaps asynchronous copies: the host tensors must be pinned"
+            with torch.cuda.stream(copy):
+                d = host.to(dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy)
+            return d, ev
+
+        nxt = next(it, None)
+        pending = upload(nxt) if nxt is not None else None
+        while pending is not None:
+            d, ev = pending
+            nxt = next(it, None)
+            pending = upload(nxt) if nxt is not None else None      # in flight while `d` computes
+            cur.wait_event(ev)
+            out = self.forward_waveforms(d)
+            d.record_stream(cur)                                     # the caching allocator must not recycle `d` early
+            yield out
+
     def capture_waveforms(self, pcm):
         """Capture forward_waveforms for inputs shaped like `pcm` into a HIP graph (eval mode only) and return a
         callable that replays it: ~45 kernel launches per step become one graph launch, which is what small

@@ -314,3 +314,20 @@ def test_bf16x3_operand_split_and_linear(ops, W):
     assert rel_err(got.cpu(), ref.cpu().numpy()) < 2e-5
     got2 = ops.merge_split(ops.linear_split(a2, w3, b, seg, relu=True, out_split=True), N)
     assert rel_err(got2.cpu(), ref.cpu().numpy()) < 2e-5
+
+
+def test_stream_waveforms_overlapped_uploads(model, W):
+    """Ensemble.stream_waveforms: pinned host batches -> scores with the upload of batch i+1 overlapping the compute of
+    batch i; results equal the resident-in-HBM path batch by batch."""
+    ens = load(model.Ensemble("repeat", dict(CNN_CONF, just_bottlenecks=False), [2, 1], torch.device("cuda"), precision="bf16"),
+               W.make_state_dict(6, W.ensemble_shapes((2, 1), False)))
+    ens.eval()
+    hosts = [torch.from_numpy(W.waveform(70 + i, 160000, 4)).pin_memory() for i in range(5)]
+    with torch.no_grad():
+        outs = [o.clone() for o in ens.stream_waveforms(hosts)]
+        assert len(outs) == 5
+        for h, o in zip(hosts, outs):
+            assert torch.equal(o, ens.forward_waveforms(h.cuda()))
+        assert list(ens.stream_waveforms([])) == []
+        with pytest.raises(AssertionError):
+            list(ens.stream_waveforms([torch.zeros(2, 160000)]))
