@@ -240,6 +240,15 @@ int dispatch(const void* a, int64_t lda, const void* w, int64_t ldw, const float
         return relu ? launch<T, TO, 4, 4, true>(a2, lda, w, ldw, bias, out2, ldo, M - m_tall, N, K, s, 1, nullptr, seg, osplit)
                     : launch<T, TO, 4, 4, false>(a2, lda, w, ldw, bias, out2, ldo, M - m_tall, N, K, s, 1, nullptr, seg, osplit);
     }
+    // 128 x 256 tiles that would leave half the CUs idle (small batches: 1 020 rows x 4096 columns = 128 tiles) run as
+    // 128 x 128 tiles instead
+    if (wide) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (((M + 127) / 128) * ((N + 255) / 256) * 2 <= cus)
+            return relu ? launch<T, TO, 4, 2, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit)
+                        : launch<T, TO, 4, 2, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit);
+    }
     if (wide) return relu ? launch<T, TO, 4, 4, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit)
                           : launch<T, TO, 4, 4, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit);
     return relu ? launch<T, TO, 4, 2, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit)
