@@ -98,7 +98,7 @@ def _linear_backward(x_in, weight, dz, g_w, g_b, want_dx):
     K-contiguous copies (reduction over rows for dW, over out-features for dx)."""
     dzT = ops.transpose_padded(dz)                         # (N, M~)
     xT = ops.transpose_padded(x_in)                        # (Kin, M~)
-    ops.linear(dzT, xT, None, out=g_w)
+    ops.linear(dzT, xT, None, out=g_w, split_k=True)
     ops.col_sum(dz, g_b)
     if not want_dx:
         return None

@@ -131,8 +131,10 @@ def conv(layer, x, w_packed, b, split=False):
     return out
 
 
-def linear(a, w, b, relu=False, out_dtype=None, out=None):
-    """a (M, K), w (N, K) same dtype (f32 | bf16), bias f32 -> (M, N) (optionally into `out`)."""
+def linear(a, w, b, relu=False, out_dtype=None, out=None, split_k=False):
+    """a (M, K), w (N, K) same dtype (f32 | bf16), bias f32 -> (M, N) (optionally into `out`). split_k: allow K to be split
+    over workgroups when there are few output tiles (weight gradients). Forward layers never split: the number of splits
+    would depend on the batch size, and a bag's scores must not depend on which batch it is computed in."""
     _chk(a); _chk(w, a.dtype)
     M, K = a.shape
     N = w.shape[0]
@@ -144,7 +146,7 @@ def linear(a, w, b, relu=False, out_dtype=None, out=None):
         assert out.is_contiguous() and out.numel() == M * N and out.dtype == out_dtype
     # few output tiles but a long reduction (weight gradients): split K over workgroups
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if a.dtype == torch.float32 and out_dtype == torch.float32 and tiles <= 64 and K >= 2048:
+    if split_k and a.dtype == torch.float32 and out_dtype == torch.float32 and tiles <= 64 and K >= 2048:
         splits = int(min(64, max(2, 256 // tiles), K // 512))
         key = "splitk/" + str(a.device)
         if key not in _ws or _ws[key].numel() < splits * M * N:

@@ -132,7 +132,9 @@ def test_vggish_embeddings_match_reference_golden(vg, golden, mk, W):
     emb = net(x)
     assert emb.dtype == torch.float32 and tuple(emb.shape) == (2, 128)
     assert rel_err(emb.cpu(), g["embedding"]) < 1e-4
-    np.testing.assert_allclose(emb.cpu().numpy(), g["embedding"], rtol=1e-4, atol=1e-5)
+    # element-wise: the first Linear is one sequential f32 chain over K = 12 288 per output (no split-K in forward layers: a
+    # bag's result must not depend on the batch it is computed in), which costs up to ~3e-5 absolute on O(10) activations
+    np.testing.assert_allclose(emb.cpu().numpy(), g["embedding"], rtol=1e-4, atol=5e-5)
     # preprocess=True: ndarray + fs -> HIP front-end -> same embedding (vggish.py:174-181)
     net2 = load(vg.VGGish(urls={}, pretrained=False, preprocess=True, postprocess=False), W.make_state_dict(1, W.vggish_shapes()))
     emb2 = net2(wav, 16000)
@@ -264,7 +266,9 @@ def test_full_size_forward_properties(model, W):
         ref = omodel.ensemble_forward({k: torch.as_tensor(v) for k, v in sd.items()}, ex, (2, 1), False)
         assert rel_err(out[:2].cpu(), ref.numpy()) < 5e-2
         ens.set_precision("f32")
-        assert rel_err(ens.forward_waveforms(pcm[:2]).cpu(), ref.numpy()) < 1e-4
+        out32 = ens.forward_waveforms(pcm[:40])
+        assert rel_err(out32[:2].cpu(), ref.numpy()) < 1e-4
+        assert torch.equal(ens.forward_waveforms(pcm[7:8]), out32[7:8])           # batch-shape invariance in the exact-f32 mode too
 
 
 @pytest.mark.parametrize("jb", [False, True])
