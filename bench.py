@@ -39,7 +39,7 @@ CONV_DESC = {"conv2": "64->128 @48x32 +pool", "conv3": "128->256 @24x16", "conv4
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "bf16x3": 2500.0}
 # HBM bytes per launch of the dominant kernel at the default batch, from rocprofv3 --pmc FETCH_SIZE (x2, gfx950)
 # + WRITE_SIZE in separate passes: profiles/r01_pmc_traffic.txt. Not measurable from inside this process.
-PMC_TRAFFIC = {("conv4", "bf16", 10240): 3.30e9}
+PMC_TRAFFIC = {("conv4", "bf16", 10240): 3.38e9}
 PEAK_HBM_GBPS = 8000.0
 
 CNN_CONF = dict(cnn_type="vggish", num_classes=10, use_pretrained=False, just_bottlenecks=False,
