@@ -153,3 +153,25 @@ def test_argument_errors_are_reported_before_any_launch(L):
     assert lib.mla_vggish_conv(2, None, None, None, None, 0, L.BF16, None) == 0
     rc = lib.mla_vggish_conv(9, fake, fake, fake, fake, 4, L.BF16, None)
     assert rc in (E_ARG, E_SHAPE) and b"layer" in lib.mla_last_error()
+
+
+def _build_c_example(L, tmp_path):
+    """gcc -std=c99 on examples/c_abi_logmel.c against include/mla_hip.h + libmla_hip.so: the header is plain C."""
+    L.lib()
+    exe = str(tmp_path / "c_abi_logmel")
+    pkg = os.path.join(ROOT, PKG)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "c_abi_logmel.c"), "-L" + pkg, "-lmla_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    return exe
+
+
+def test_c_host_compiles_against_the_header(L, tmp_path):
+    assert os.path.exists(_build_c_example(L, tmp_path))
+
+
+@pytest.mark.gpu
+def test_c_host_runs(L, tmp_path):
+    """The plain-C host (no Python, no torch in the process) produces examples and sees the reference's short-input error."""
+    out = subprocess.run([_build_c_example(L, tmp_path)], check=True, capture_output=True, text=True).stdout
+    assert "examples (40, 96, 64)" in out and "rc -3" in out, out
