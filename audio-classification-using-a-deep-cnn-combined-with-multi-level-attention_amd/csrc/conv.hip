@@ -252,7 +252,8 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
         b_dma(0, 0, 0);
         a_write();
     }
-    __syncthreads();                               // (drains the DMA: hipcc waits vmcnt(0) in front of the barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     // One barrier per tap. The weight pipeline runs continuously across channel chunks AND across tiles (slice g+1 is
     // DMA'd into the other LDS buffer under the MFMAs of slice g); the next chunk's / next tile's input patch is DMA'd
@@ -299,7 +300,11 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                         _Pragma("unroll") for (int j = 0; j < C::NS; ++j) mma_step<T>(af[i], bf[j], acc[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                __syncthreads();                   // DMA landed (vmcnt(0) precedes the barrier) and every wave is done with `cur`
+                // The DMA'd slice must have landed before the barrier that publishes it: LDS-DMA is ordered for a ds_read only
+                // by the issuing wave's vmcnt followed by a barrier. hipcc emits this wait itself in front of
+                // __syncthreads() while a DMA is in flight; it is spelled out so correctness does not rest on that.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                   // ... and every wave is done with `cur`
                 if constexpr (C::A_DMA) {
                     if (tap == 8 && new_patch) abuf ^= 1;
                 } else {

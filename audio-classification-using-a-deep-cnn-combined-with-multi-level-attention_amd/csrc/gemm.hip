@@ -113,6 +113,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
     const int stages = (s_begin + per_split < all_stages ? s_begin + per_split : all_stages);
     if (DMA) {
         dma(s_begin, s_begin & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // DMA data is ordered for ds_read by vmcnt + barrier only
     } else {
         gload(s_begin);
         lwrite(s_begin & 1);
@@ -136,7 +137,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!DMA && s + 1 < stages) lwrite(buf ^ 1);   // the other buffer was last read before the previous barrier
-        __syncthreads();                               // (with a DMA in flight hipcc waits vmcnt(0) in front of the barrier)
+        if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
 
     if (partial) {                          // raw sums of this K range; bias / activation happen in the reduction
