@@ -410,8 +410,8 @@ __global__ __launch_bounds__(256, 4) void conv1_kernel(const TIN* __restrict__ x
             uint32_t pk[4];
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {
                 const int t0 = 8 * q + 2 * e, t1 = t0 + 1;
-                const float v0 = t0 < 9 ? w[(16 * j + r) * 9 + t0] : 0.f, v1 = t1 < 9 ? w[(16 * j + r) * 9 + t1] : 0.f;
-                pk[e] = f2bf(v0) | (uint32_t(f2bf(v1)) << 16);
+                const float v0 = t0 < 9 ? w[(4 * r + j) * 9 + t0] : 0.f, v1 = t1 < 9 ? w[(4 * r + j) * 9 + t1] : 0.f;
+                pk[e] = pack_bf16x2(v0, v1);
             }
             wf.b[j] = u32x4{pk[0], pk[1], pk[2], pk[3]};
         }
@@ -422,12 +422,13 @@ __global__ __launch_bounds__(256, 4) void conv1_kernel(const TIN* __restrict__ x
     } else {
         _Pragma("unroll") for (int s3 = 0; s3 < 3; ++s3) {
             const int tt = 4 * s3 + q;
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) wf.b[s3][j] = tt < 9 ? w[(16 * j + r) * 9 + tt] : 0.f;
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) wf.b[s3][j] = tt < 9 ? w[(4 * r + j) * 9 + tt] : 0.f;
             toff[s3] = tt < 9 ? (tt / 3) * PITCH + tt % 3 + r : 10 * PITCH;
         }
     }
     float bj[4];
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) bj[j] = bias[16 * j + r];
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) bj[j] = bias[4 * r + j];      // MFMA column r of subtile j = output channel 4 r + j:
+                                                                                 // a lane's four subtile values are 4 consecutive channels
 
     // persistent over tiles: weights / offsets load once; the next tile's patch is in flight during the MFMAs
     char* stage = sOut + wave * 32 * ROW;
@@ -446,8 +447,7 @@ __global__ __launch_bounds__(256, 4) void conv1_kernel(const TIN* __restrict__ x
             if constexpr (sizeof(T) == 2) {
                 float v[8];
                 _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] = sX[toff[e] + shift];
-                const u32x4 a = u32x4{f2bf(v[0]) | (uint32_t(f2bf(v[1])) << 16), f2bf(v[2]) | (uint32_t(f2bf(v[3])) << 16),
-                                      f2bf(v[4]) | (uint32_t(f2bf(v[5])) << 16), f2bf(v[6]) | (uint32_t(f2bf(v[7])) << 16)};
+                const u32x4 a = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
                 _Pragma("unroll") for (int j = 0; j < 4; ++j) mma_step<bf16_t>(a, wf.b[j], acc[i][j]);
             } else {
                 _Pragma("unroll") for (int s3 = 0; s3 < 3; ++s3) {
@@ -457,22 +457,29 @@ __global__ __launch_bounds__(256, 4) void conv1_kernel(const TIN* __restrict__ x
                 }
             }
         }
-        // 2x2 pool (lane-local), bias, ReLU -> LDS stage [pooled x][64 ch]
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {
-            const f32x4 u = acc[0][j], d = acc[1][j];
-            const float p0 = fmaxf(fmaxf(fmaxf(u.x, u.y), fmaxf(d.x, d.y)) + bj[j], 0.f);
-            const float p1 = fmaxf(fmaxf(fmaxf(u.z, u.w), fmaxf(d.z, d.w)) + bj[j], 0.f);
+        // 2x2 pool (lane-local), bias, ReLU -> LDS stage [pooled x][64 ch]: the lane's four channels 4r .. 4r+3 as one piece
+        {
+            float p0[4], p1[4];
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {
+                const f32x4 u = acc[0][j], d = acc[1][j];
+                p0[j] = fmaxf(fmaxf(fmaxf(u.x, u.y), fmaxf(d.x, d.y)) + bj[j], 0.f);
+                p1[j] = fmaxf(fmaxf(fmaxf(u.z, u.w), fmaxf(d.z, d.w)) + bj[j], 0.f);
+            }
             const int xo = 8 * seg + 2 * q;
             if constexpr (SPLIT) {        // f32 arithmetic, [hi(64) | lo(64)] bf16 per pooled pixel = the f32 row's 256 bytes
                 static_assert(!SPLIT || sizeof(T) == 4, "split output is produced by the exact-f32 path");
-                bf16_t* s0 = reinterpret_cast<bf16_t*>(stage + xo * ROW) + 16 * j + r;
-                bf16_t* s1 = reinterpret_cast<bf16_t*>(stage + (xo + 1) * ROW) + 16 * j + r;
-                const float h0 = bf2f(f2bf(p0)), h1 = bf2f(f2bf(p1));
-                s0[0].bits = f2bf(h0); s0[64].bits = f2bf(p0 - h0);
-                s1[0].bits = f2bf(h1); s1[64].bits = f2bf(p1 - h1);
+                float h0[4], h1[4], l0[4], l1[4];
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {
+                    h0[j] = bf2f(f2bf(p0[j])); l0[j] = p0[j] - h0[j];
+                    h1[j] = bf2f(f2bf(p1[j])); l1[j] = p1[j] - h1[j];
+                }
+                bf16_t* s0 = reinterpret_cast<bf16_t*>(stage + xo * ROW) + 4 * r;
+                bf16_t* s1 = reinterpret_cast<bf16_t*>(stage + (xo + 1) * ROW) + 4 * r;
+                store_vec<bf16_t, 4>(s0, h0); store_vec<bf16_t, 4>(s0 + 64, l0);
+                store_vec<bf16_t, 4>(s1, h1); store_vec<bf16_t, 4>(s1 + 64, l1);
             } else {
-                store_elem<T>(reinterpret_cast<T*>(stage + xo * ROW) + 16 * j + r, p0);
-                store_elem<T>(reinterpret_cast<T*>(stage + (xo + 1) * ROW) + 16 * j + r, p1);
+                store_vec<T, 4>(reinterpret_cast<T*>(stage + xo * ROW) + 4 * r, p0);
+                store_vec<T, 4>(reinterpret_cast<T*>(stage + (xo + 1) * ROW) + 4 * r, p1);
             }
         }
     }
