@@ -91,6 +91,28 @@ MLA_HD void dft4_z3(float& r0, float& i0, float& r1, float& i1, float& r2, float
     r3 = t1r - xi; i3 = t1i + xr;
 }
 
+// dft4 with input 2 given as u2 / R (R = sqrt(1/2)): the scaling rides in the first butterfly's FMAs
+MLA_HD void dft4_s2(float& r0, float& i0, float& r1, float& i1, float& u2r, float& u2i, float& r3, float& i3) {
+    constexpr float R = 0.70710678118654752440f;
+    const float t0r = r0 + R * u2r, t0i = i0 + R * u2i, t1r = r0 - R * u2r, t1i = i0 - R * u2i;
+    const float t2r = r1 + r3, t2i = i1 + i3, t3r = r1 - r3, t3i = i1 - i3;
+    r0 = t0r + t2r; i0 = t0i + t2i;
+    u2r = t0r - t2r; u2i = t0i - t2i;
+    r1 = t1r + t3i; i1 = t1i - t3r;
+    r3 = t1r - t3i; i3 = t1i + t3r;
+}
+// dft4 with inputs 1 and 3 given as u1 / R and u3 / R: t2 = R (u1 + u3), t3 = R (u1 - u3) are never formed, the scaling
+// rides in the second butterfly's FMAs
+MLA_HD void dft4_s13(float& r0, float& i0, float& u1r, float& u1i, float& r2, float& i2, float& u3r, float& u3i) {
+    constexpr float R = 0.70710678118654752440f;
+    const float t0r = r0 + r2, t0i = i0 + i2, t1r = r0 - r2, t1i = i0 - i2;
+    const float sr = u1r + u3r, si = u1i + u3i, dr = u1r - u3r, di = u1i - u3i;
+    r0 = t0r + R * sr; i0 = t0i + R * si;
+    r2 = t0r - R * sr; i2 = t0i - R * si;
+    u1r = t1r + R * di; u1i = t1i - R * dr;       // t1 - i t3
+    u3r = t1r - R * di; u3i = t1i + R * dr;       // t1 + i t3
+}
+
 MLA_HD void cmul(float& r, float& i, float p, float q) {   // (r + i i) *= (p + i q)
     const float nr = r * p - i * q, ni = r * q + i * p;
     r = nr; i = ni;
@@ -117,19 +139,21 @@ MLA_HD void dft16(float* re, float* im) {
     }
     // step 2: y_b[c] *= W16^(b c), element 4c + b; W16^m = (cos, -sin)(2 pi m / 16)
     cmul(re[5], im[5], C1, -S1);                                   // b=1,c=1: m=1
-    { const float a = re[6], b = im[6]; re[6] = R * (a + b); im[6] = R * (b - a); }      // m=2
+    // the four twiddles of modulus-R components, (1 - i) R (m = 2) and -(1 + i) R (m = 6), are applied WITHOUT their factor
+    // R = sqrt(1/2): it is folded into the FMAs of the following DFT4 (dft4_s2 / dft4_s13)
+    { const float a = re[6], b = im[6]; re[6] = a + b; im[6] = b - a; }                  // m=2 (x R)
     cmul(re[7], im[7], S1, -C1);                                   // b=3,c=1: m=3
-    { const float a = re[9], b = im[9]; re[9] = R * (a + b); im[9] = R * (b - a); }      // b=1,c=2: m=2
+    { const float a = re[9], b = im[9]; re[9] = a + b; im[9] = b - a; }                  // b=1,c=2: m=2 (x R)
     { const float a = re[10], b = im[10]; re[10] = b; im[10] = -a; }                     // m=4: -i
-    { const float a = re[11], b = im[11]; re[11] = R * (b - a); im[11] = -R * (a + b); } // m=6
+    { const float a = re[11], b = im[11]; re[11] = b - a; im[11] = -(a + b); }           // m=6 (x R)
     cmul(re[13], im[13], S1, -C1);                                 // b=1,c=3: m=3
-    { const float a = re[14], b = im[14]; re[14] = R * (b - a); im[14] = -R * (a + b); } // m=6
+    { const float a = re[14], b = im[14]; re[14] = b - a; im[14] = -(a + b); }           // m=6 (x R)
     cmul(re[15], im[15], -C1, S1);                                 // b=3,c=3: m=9
     // step 3: DFT4 over b for each c: elements 4c .. 4c+3 -> X[c + 4d] at 4c + d
     dft4(re[0], im[0], re[1], im[1], re[2], im[2], re[3], im[3]);
-    dft4(re[4], im[4], re[5], im[5], re[6], im[6], re[7], im[7]);
-    dft4(re[8], im[8], re[9], im[9], re[10], im[10], re[11], im[11]);
-    dft4(re[12], im[12], re[13], im[13], re[14], im[14], re[15], im[15]);
+    dft4_s2(re[4], im[4], re[5], im[5], re[6], im[6], re[7], im[7]);
+    dft4_s13(re[8], im[8], re[9], im[9], re[10], im[10], re[11], im[11]);
+    dft4_s2(re[12], im[12], re[13], im[13], re[14], im[14], re[15], im[15]);
 }
 
 // phase 1: lane j = n2. phase1_window: windowed samples of the lane, z[16 n1 + j] = (x w)[32 n1 + 2 j] +
