@@ -84,6 +84,8 @@ def lib():
         L.mla_conv_repack_dgrad.argtypes = [vp, i64, i64, vp, vp]
         L.mla_maxpool2x2.argtypes = [vp, vp, i64, ci, ci, ci, vp]
         L.mla_relu_pool_bwd.argtypes = [vp, vp, vp, i64, ci, ci, ci, ci, vp]
+        L.mla_relu_pool_bwd_bias.argtypes = [vp, vp, vp, i64, ci, ci, ci, ci, vp, vp, vp]
+        L.mla_relu_pool_bwd_bias_workspace_bytes.restype = ctypes.c_int64
         L.mla_conv_wgrad_workspace_floats.restype = i64
         L.mla_conv_wgrad.argtypes = [vp, vp, i64, ci, ci, ci, ci, vp, i64, vp, vp]
         L.mla_conv1_bwd.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp]

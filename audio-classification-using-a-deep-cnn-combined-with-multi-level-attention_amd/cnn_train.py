@@ -67,9 +67,8 @@ def backward(cnn_model, tape, d_out, grads, prefix):
         cin, cout, H, W_, pooled = GEOM[layer]
         a_in, a = tape["layers"][layer]
         key = prefix + kf + "%d." % conv_idx[layer - 1]
-        dz = ops.relu_pool_bwd(a, d.contiguous(), pool=pooled)
+        dz = ops.relu_pool_bwd(a, d.contiguous(), pool=pooled, db=grads[key + "bias"])     # bias gradient summed on the way
         ops.conv_wgrad(dz, a_in, grads[key + "weight"])
-        ops.col_sum(dz.reshape(-1, cout), grads[key + "bias"])
         wd = ops.repack_dgrad(convs[layer - 1].weight.detach().contiguous())
         d = ops.conv3x3(dz, wd, None, cin, pool=False, act=False)
     key = prefix + kf + "0."

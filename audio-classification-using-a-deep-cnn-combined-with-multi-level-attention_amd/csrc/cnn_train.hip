@@ -75,6 +75,57 @@ __global__ __launch_bounds__(256) void relu_pool_bwd_kernel(const float* __restr
     }
 }
 
+// Same, and the bias gradient db[c] = sum over pixels of dZ[., c] on the way (it used to be a second pass over dZ, the largest
+// tensor of the backward pass). The grid-stride step is a multiple of C, so a thread's channel never changes: each thread sums
+// its elements in double precision into slot blockIdx * 256 + t; slot s belongs to channel s % C.
+__global__ __launch_bounds__(256) void relu_pool_bwd_bias_kernel(const float* __restrict__ a, const float* __restrict__ d_out,
+                                                                 float* __restrict__ dz, int64_t total, int H, int W, int C, int pool,
+                                                                 double* __restrict__ slots) {
+    double acc = 0.0;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < total; i += int64_t(gridDim.x) * 256) {
+        if (!pool) {
+            const float g = a[i] > 0.f ? d_out[i] : 0.f;
+            dz[i] = g;
+            acc += g;
+            continue;
+        }
+        const int WO = W / 2, HO = H / 2;
+        const int c = int(i % C);
+        int64_t r = i / C;
+        const int xo = int(r % WO); r /= WO;
+        const int yo = int(r % HO);
+        const int64_t n = r / HO;
+        const int64_t base = ((n * H + 2 * yo) * W + 2 * xo) * C + c;
+        const int64_t off[4] = {0, C, int64_t(W) * C, int64_t(W) * C + C};
+        float best = a[base];
+        int arg = 0;
+        _Pragma("unroll") for (int k = 1; k < 4; ++k) {
+            const float v = a[base + off[k]];
+            if (v > best) { best = v; arg = k; }
+        }
+        const float g = best > 0.f ? d_out[i] : 0.f;
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) dz[base + off[k]] = (k == arg) ? g : 0.f;
+        acc += g;
+    }
+    slots[int64_t(blockIdx.x) * 256 + threadIdx.x] = acc;
+}
+
+// db[c] = sum of the slots of channel c (slots c, c + C, ...), one workgroup per channel, fixed order
+__global__ __launch_bounds__(256) void bias_slots_finish_kernel(const double* __restrict__ slots, int64_t n_slots, int C,
+                                                                float* __restrict__ db) {
+    __shared__ double part[256];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int64_t k = int64_t(c) + int64_t(threadIdx.x) * C; k < n_slots; k += int64_t(256) * C) s += slots[k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (int(threadIdx.x) < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) db[c] = float(part[0]);
+}
+
 // ------------------------------------------------------------------------------------ wgrad ---
 constexpr int kPix = 80;                 // LDS floats per pixel row: 64 channels + 16 pad (bank spread for k = pixel)
 
@@ -282,6 +333,26 @@ extern "C" int mla_relu_pool_bwd(const float* a, const float* d_out, float* dz, 
     const unsigned grid = unsigned((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(relu_pool_bwd_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a, d_out, dz, total, H, W, C, pool);
     MLA_LAUNCH_OK("relu_pool_bwd");
+    return MLA_OK;
+}
+
+constexpr int kBiasGrid = 4096;            // workgroups of relu_pool_bwd_bias_kernel (a multiple of C / 256 for C <= 1024)
+
+extern "C" int64_t mla_relu_pool_bwd_bias_workspace_bytes(void) { return int64_t(kBiasGrid) * 256 * 8; }
+
+extern "C" int mla_relu_pool_bwd_bias(const float* a, const float* d_out, float* dz, int64_t n, int H, int W, int C, int pool,
+                                      void* workspace, float* db, mla_stream_t stream) {
+    MLA_REQUIRE(a && d_out && dz && workspace && db && n > 0, MLA_E_ARG, "bad relu_pool_bwd_bias arguments");
+    MLA_REQUIRE(C > 0 && (kBiasGrid * 256) % C == 0, MLA_E_SHAPE, "channel count %d must divide %d", C, kBiasGrid * 256);
+    MLA_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0), MLA_E_SHAPE, "pooling needs even H, W");
+    const int64_t total = pool ? n * (H / 2) * (W / 2) * C : n * H * W * C;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(relu_pool_bwd_bias_kernel, dim3(kBiasGrid), dim3(256), 0, s, a, d_out, dz, total, H, W, C, pool,
+                       static_cast<double*>(workspace));
+    MLA_LAUNCH_OK("relu_pool_bwd_bias");
+    hipLaunchKernelGGL(bias_slots_finish_kernel, dim3(unsigned(C)), dim3(256), 0, s, static_cast<const double*>(workspace),
+                       int64_t(kBiasGrid) * 256, C, db);
+    MLA_LAUNCH_OK("bias_slots_finish");
     return MLA_OK;
 }
 

@@ -379,13 +379,21 @@ def maxpool2x2(a):
     return out
 
 
-def relu_pool_bwd(a, d_out, pool):
-    """dZ at a's resolution from the gradient of relu(.) [pool == 0] or maxpool(relu(.)) [pool == 1]."""
+def relu_pool_bwd(a, d_out, pool, db=None):
+    """dZ at a's resolution from the gradient of relu(.) [pool == 0] or maxpool(relu(.)) [pool == 1]; db (C,): also the
+    bias gradient = column sums of dZ, accumulated in the same pass."""
     _chk(a, torch.float32); _chk(d_out, torch.float32)
     a4 = a if a.dim() == 4 else a.reshape(a.shape[0], 1, 1, -1)
     n, H, W_, C = a4.shape
     dz = torch.empty_like(a)
-    _lib.check(_lib.lib().mla_relu_pool_bwd(_p(a), _p(d_out), _p(dz), n, H, W_, C, int(pool), _lib.stream_ptr()))
+    if db is None:
+        _lib.check(_lib.lib().mla_relu_pool_bwd(_p(a), _p(d_out), _p(dz), n, H, W_, C, int(pool), _lib.stream_ptr()))
+        return dz
+    _chk(db, torch.float32)
+    key = "biasws/" + str(a.device)
+    if key not in _ws:
+        _ws[key] = torch.empty(int(_lib.lib().mla_relu_pool_bwd_bias_workspace_bytes()) // 8, dtype=torch.float64, device=a.device)
+    _lib.check(_lib.lib().mla_relu_pool_bwd_bias(_p(a), _p(d_out), _p(dz), n, H, W_, C, int(pool), _p(_ws[key]), _p(db), _lib.stream_ptr()))
     return dz
 
 

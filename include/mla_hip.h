@@ -277,6 +277,11 @@ int mla_maxpool2x2(const float* a, float* out, int64_t n, int H, int W, int C, m
  * masked by ReLU; pool == 0: dZ = d_out * (a > 0). */
 int mla_relu_pool_bwd(const float* a, const float* d_out, float* dz, int64_t n, int H, int W, int C, int pool,
                       mla_stream_t stream);
+/* the same plus the layer's bias gradient db[C] = column sums of dZ (nn.Conv2d bias, loss.backward() train.py:137), summed
+ * on the way in double precision; workspace: mla_relu_pool_bwd_bias_workspace_bytes() bytes */
+int64_t mla_relu_pool_bwd_bias_workspace_bytes(void);
+int mla_relu_pool_bwd_bias(const float* a, const float* d_out, float* dz, int64_t n, int H, int W, int C, int pool,
+                           void* workspace, float* db, mla_stream_t stream);
 /* dW (Cout, Cin, 3, 3) = sum over pixels of dZ (n,H,W,Cout) x shifted a_in (n,H,W,Cin); f32 MFMA,
  * deterministic split reduction. workspace: mla_conv_wgrad_workspace_floats() floats. */
 int64_t mla_conv_wgrad_workspace_floats(void);
