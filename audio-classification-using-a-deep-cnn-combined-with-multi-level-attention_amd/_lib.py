@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MLA_HIP_LIB") or os.path.join(HERE, "libmla_hip.so")   # MLA_HIP_LIB: an alternative build (A/B measurements)
 HEADER = os.path.join(os.path.dirname(HERE), "include", "mla_hip.h")
 
-F32, BF16, I16, BF16X3 = 0, 1, 2, 3
+F32, BF16, I16, BF16X3, F64, I32 = 0, 1, 2, 3, 4, 5
 E_SHORT = -3
 
 _lib = None
@@ -89,6 +89,13 @@ def lib():
         L.mla_conv_wgrad_workspace_floats.restype = i64
         L.mla_conv_wgrad.argtypes = [vp, vp, i64, ci, ci, ci, ci, vp, i64, vp, vp]
         L.mla_conv1_bwd.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp]
+        u64 = ctypes.c_uint64
+        L.mla_dropout_mask.argtypes = [vp, i64, u64, u64, u64, cf, vp]
+        L.mla_comm_unique_id.argtypes = [vp]
+        L.mla_comm_init_rank.argtypes = [ctypes.POINTER(vp), ci, vp, ci]
+        L.mla_comm_destroy.argtypes = [vp]
+        L.mla_comm_library_origin.restype = ctypes.c_char_p
+        L.mla_allreduce_flat.argtypes = [vp, i64, ci, vp, vp]
         _lib = L
     return _lib
 

@@ -52,9 +52,9 @@ def build(force=False, verbose=True):
         results = list(ex.map(lambda s: _compile(s, force, hdr_ts), sources()))
     objs = [o for o, _ in results]
     if any(changed for _, changed in results) or not os.path.exists(LIB):
-        link = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
-        # no -lrccl: collectives go through torch.distributed (backend "nccl" = the RCCL build PyTorch ships); a second
-        # RCCL in the process (ROCm's) would only add two sets of nccl* symbols to the global namespace
+        link = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl"]
+        # no -lrccl: csrc/collective.hip binds the RCCL already loaded in the process (the build PyTorch ships, or the C
+        # host's own) with dlopen(RTLD_NOLOAD) at first use; linking ROCm's here would put a second RCCL beside it
         subprocess.run(link, check=True)
         if verbose:
             print("built", LIB)

@@ -49,28 +49,46 @@ def forward(cnn_model, x):
 
 
 def backward(cnn_model, tape, d_out, grads, prefix):
-    """d_out: gradient w.r.t. forward()'s result. Fills grads[prefix + <state_dict key>] for every CNN
-    parameter (weights in state_dict layout)."""
+    """d_out: gradient w.r.t. forward()'s result. Fills grads[prefix + <state_dict key>] for every CNN parameter that HAS
+    an entry in `grads` (weights in state_dict layout). Parameters without an entry get no gradient (they are frozen or
+    not held by the caller's optimizer), and the chain of input gradients stops at the lowest layer that has one."""
     feats, fcs, kf, ke = _parts(cnn_model)
     convs = feats._convs
     conv_idx = [0, 3, 6, 8, 11, 13]
     fc_idx = [0, 2, 4]
+    g = lambda key: grads.get(key)
+    conv_keys = [prefix + kf + "%d." % i for i in conv_idx]
+    fc_keys = [prefix + ke + "%d." % i for i in fc_idx[:len(fcs)]] if fcs else []
+    order = conv_keys + fc_keys                                     # bottom -> top
+    wanted = [k + "weight" in grads or k + "bias" in grads for k in order]
+    if not any(wanted):
+        return
+    lowest = wanted.index(True)
     d = d_out.contiguous()
     for i in range(len(fcs) - 1, -1, -1):
+        pos = 6 + i
+        if pos < lowest:
+            return
         h_in, h_out = tape["fc"][i]
         dz = ops.relu_pool_bwd(h_out, d, pool=False)
-        key = prefix + ke + "%d." % fc_idx[i]
-        d = mla_train._linear_backward(h_in, fcs[i].weight.detach(), dz, grads[key + "weight"], grads[key + "bias"], True)
+        key = fc_keys[i]
+        d = mla_train._linear_backward(h_in, fcs[i].weight.detach(), dz, g(key + "weight"), g(key + "bias"), pos > lowest)
     n = tape["x"].shape[0]
-    d = d.reshape(n, 6, 4, 512)
     for layer in range(6, 1, -1):
+        pos = layer - 1
+        if pos < lowest:
+            return
+        d = d.reshape(n, 6, 4, 512) if layer == 6 else d
         cin, cout, H, W_, pooled = GEOM[layer]
         a_in, a = tape["layers"][layer]
-        key = prefix + kf + "%d." % conv_idx[layer - 1]
-        dz = ops.relu_pool_bwd(a, d.contiguous(), pool=pooled, db=grads[key + "bias"])     # bias gradient summed on the way
-        ops.conv_wgrad(dz, a_in, grads[key + "weight"])
-        wd = ops.repack_dgrad(convs[layer - 1].weight.detach().contiguous())
-        d = ops.conv3x3(dz, wd, None, cin, pool=False, act=False)
-    key = prefix + kf + "0."
-    ops.conv1_bwd(tape["x"], convs[0].weight.detach().contiguous(), convs[0].bias.detach(), d.contiguous(),
-                  grads[key + "weight"], grads[key + "bias"])
+        key = conv_keys[pos]
+        dz = ops.relu_pool_bwd(a, d.contiguous(), pool=pooled, db=g(key + "bias"))     # bias gradient summed on the way
+        if g(key + "weight") is not None:
+            ops.conv_wgrad(dz, a_in, g(key + "weight"))
+        if pos > lowest:
+            wd = ops.repack_dgrad(convs[layer - 1].weight.detach().contiguous())
+            d = ops.conv3x3(dz, wd, None, cin, pool=False, act=False)
+    key = conv_keys[0]
+    dw = g(key + "weight") if g(key + "weight") is not None else torch.empty((64, 1, 3, 3), dtype=torch.float32, device=d.device)
+    db = g(key + "bias") if g(key + "bias") is not None else torch.empty(64, dtype=torch.float32, device=d.device)
+    ops.conv1_bwd(tape["x"], convs[0].weight.detach().contiguous(), convs[0].bias.detach(), d.contiguous(), dw, db)

@@ -27,14 +27,18 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 
 // loss = inv_total * sum_b (logsumexp(x_b) - x_b[y_b]);  dx = inv_total * (softmax(x_b) - onehot(y_b))
 // one block: deterministic double-precision reduction. inv_total = 1 / (global batch).
+// A label outside [0, K) (nn.CrossEntropyLoss raises "Target out of bounds" for it) is never used as an index: the row
+// contributes nothing, the loss comes out NaN and *n_correct = -(number of such labels), which the host layer turns into
+// the exception (ops.cross_entropy / train_model) without a per-step synchronisation of its own.
 __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ x, int64_t ldx,
                                                             const int64_t* __restrict__ labels, int64_t rows, int K,
                                                             float inv_total, float* __restrict__ loss, float* __restrict__ dx,
                                                             int64_t ld_dx, int* __restrict__ n_correct) {
     __shared__ double part[256];
     __shared__ int hits[256];
+    __shared__ int bads[256];
     double acc = 0.0;
-    int correct = 0;
+    int correct = 0, bad = 0;
     for (int64_t b = threadIdx.x; b < rows; b += 256) {
         const float* row = x + b * ldx;
         float mx = row[0];
@@ -44,22 +48,30 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
         float den = 0.f;
         for (int k = 0; k < K; ++k) den += __expf(row[k] - mx);
         const float lse = mx + __logf(den);
-        const int y = int(labels[b]);
-        acc += double(lse - row[y]);
+        const int64_t y64 = labels[b];
+        const bool ok = y64 >= 0 && y64 < K;
+        const int y = ok ? int(y64) : -1;
+        bad += !ok;
+        if (ok) acc += double(lse - row[y]);
         correct += (arg == y);
         if (dx)
-            for (int k = 0; k < K; ++k) dx[b * ld_dx + k] = (__expf(row[k] - lse) - (k == y ? 1.f : 0.f)) * inv_total;
+            for (int k = 0; k < K; ++k) dx[b * ld_dx + k] = ok ? (__expf(row[k] - lse) - (k == y ? 1.f : 0.f)) * inv_total : 0.f;
     }
     part[threadIdx.x] = acc;
     hits[threadIdx.x] = correct;
+    bads[threadIdx.x] = bad;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) { part[threadIdx.x] += part[threadIdx.x + o]; hits[threadIdx.x] += hits[threadIdx.x + o]; }
+        if (threadIdx.x < o) {
+            part[threadIdx.x] += part[threadIdx.x + o];
+            hits[threadIdx.x] += hits[threadIdx.x + o];
+            bads[threadIdx.x] += bads[threadIdx.x + o];
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        *loss = float(part[0] * inv_total);
-        if (n_correct) *n_correct = hits[0];
+        *loss = bads[0] ? __builtin_nanf("") : float(part[0] * inv_total);
+        if (n_correct) *n_correct = bads[0] ? -bads[0] : hits[0];
     }
 }
 
@@ -102,6 +114,31 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         m[i] = mi;
         v[i] = vi;
         p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+
+// splitmix64 finaliser; the same three lines as weights.py _mix (uint64 wrap-around arithmetic only)
+__host__ __device__ inline uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// 16 mask bytes per thread and store (one dwordx4): HBM-write-bound, 1 B per element
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ mask, int64_t n, uint64_t key, uint64_t offset,
+                                                           uint32_t thresh) {
+    const uint64_t gold = 0x9E3779B97F4A7C15ull;
+    for (int64_t i0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) * 16; i0 < n; i0 += int64_t(gridDim.x) * blockDim.x * 16) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        _Pragma("unroll") for (int j = 0; j < 16; ++j) {
+            const uint64_t z = mix64((offset + uint64_t(i0 + j)) * gold + key);
+            w[j >> 2] |= uint32_t(uint32_t(z >> 40) >= thresh) << (8 * (j & 3));
+        }
+        if (i0 + 16 <= n && (reinterpret_cast<uintptr_t>(mask + i0) & 15) == 0) {
+            *reinterpret_cast<uint4*>(mask + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            for (int j = 0; j < 16 && i0 + j < n; ++j) mask[i0 + j] = uint8_t(w[j >> 2] >> (8 * (j & 3)));
+        }
     }
 }
 
@@ -158,5 +195,17 @@ extern "C" int mla_adam_step(float* p, const float* g, float* m, float* v, int64
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n, beta1, beta2,
                        eps, float(double(lr) / bc1), float(1.0 / sqrt(bc2)));
     MLA_LAUNCH_OK("adam");
+    return MLA_OK;
+}
+
+extern "C" int mla_dropout_mask(uint8_t* mask, int64_t n, uint64_t seed, uint64_t stream_id, uint64_t offset, float p_drop,
+                                mla_stream_t stream) {
+    MLA_REQUIRE(mask && n >= 0 && p_drop >= 0.f && p_drop <= 1.f, MLA_E_ARG, "bad dropout_mask arguments");
+    if (n == 0) return MLA_OK;
+    const uint64_t key = mix64(seed * 0x9E3779B97F4A7C15ull + stream_id);
+    const uint32_t thresh = uint32_t(llround(double(p_drop) * double(1 << 24)));
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((n + 15) / 16)), dim3(256), 0, static_cast<hipStream_t>(stream), mask, n, key,
+                       offset, thresh);
+    MLA_LAUNCH_OK("dropout_mask");
     return MLA_OK;
 }

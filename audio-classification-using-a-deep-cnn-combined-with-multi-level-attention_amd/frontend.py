@@ -42,20 +42,24 @@ def _device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
-def as_device_mono(data):
-    """ndarray / tensor, 1-D or (samples, channels) -> 1-D device tensor, float32 or int16.
+def as_device_mono(data, pcm16=False):
+    """ndarray / tensor, 1-D or (samples, channels) -> 1-D device tensor.
 
-    Mono int16 stays int16 (the log-mel kernel scales by 1/32768 itself). Multi-channel input is averaged over
-    axis 1 as vggish_input.py:49-50 does, by `mla_mono_mix` on the device (double-precision mean, one rounding).
+    pcm16=False (the public ``waveform_to_examples``, vggish_input.py:30-82, which never scales its input): integer
+    arrays are converted to float32 VALUES as they are, like numpy's promotion in the reference.
+    pcm16=True (``wavfile_to_examples`` and the PCM streaming paths, vggish_input.py:97-98 ``wav_data / 32768.0``): mono
+    int16 stays int16 and the log-mel kernel scales by 1/32768 in its PCM read; multi-channel int16 is scaled in the mix.
+    Multi-channel input is averaged over axis 1 as vggish_input.py:49-50 does, by `mla_mono_mix` on the device
+    (double-precision mean, one rounding).
     """
     dev = _device()
     if isinstance(data, np.ndarray):
-        if data.dtype != np.int16:
+        if data.dtype != np.int16 or not pcm16:
             data = data.astype(np.float32, copy=False)     # float64 reference input: rounded once, like the mono path
         t = torch.from_numpy(np.array(data, order="C", copy=True) if not data.flags.writeable else np.ascontiguousarray(data)).to(dev)
     else:
         t = data.to(dev)
-        if t.dtype != torch.int16:
+        if t.dtype != torch.int16 or not pcm16:
             t = t.float()
         t = t.contiguous()
     if t.dim() == 1:

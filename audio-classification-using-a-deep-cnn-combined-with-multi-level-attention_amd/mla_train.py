@@ -39,7 +39,7 @@ def embedded_mapping_forward(em, x, ctx=None):
     for j in range(em.n_fc):
         z = ops.linear(h, em.fc[j].weight.detach(), em.fc[j].bias.detach())
         mean, var = _bn_stats(em.norms[j], z, 0, T, train, ctx)
-        keep = em.dropouts[j].keep_mask(z.numel(), z.device) if train else None
+        keep = em.dropouts[j].keep_mask(z.numel(), z.device, offset=ctx.dist.rank * z.numel()) if train else None
         h_in = h
         h = ops.bn_apply(z, 0, T, mean, var, em.norms[j].weight.detach(), em.norms[j].bias.detach(), act=1,
                          keep_mask=keep, drop_scale=1.0 / (1.0 - DR))
@@ -95,11 +95,13 @@ def mla_apply(mla, x):
 
 def _linear_backward(x_in, weight, dz, g_w, g_b, want_dx):
     """out = x_in W^T + b: dW = dz^T x_in, db = column sums, dx = dz W -- MFMA GEMMs on transposed,
-    K-contiguous copies (reduction over rows for dW, over out-features for dx)."""
-    dzT = ops.transpose_padded(dz)                         # (N, M~)
-    xT = ops.transpose_padded(x_in)                        # (Kin, M~)
-    ops.linear(dzT, xT, None, out=g_w, split_k=True)
-    ops.col_sum(dz, g_b)
+    K-contiguous copies (reduction over rows for dW, over out-features for dx). g_w / g_b None: that gradient is not wanted."""
+    if g_w is not None:
+        dzT = ops.transpose_padded(dz)                         # (N, M~)
+        xT = ops.transpose_padded(x_in)                        # (Kin, M~)
+        ops.linear(dzT, xT, None, out=g_w, split_k=True)
+    if g_b is not None:
+        ops.col_sum(dz, g_b)
     if not want_dx:
         return None
     wT = ops.transpose_padded(weight)                      # (Kin, N~)

@@ -38,19 +38,28 @@ class BatchNorm1d(nn.Module):
 
 
 class Dropout(nn.Module):
-    """nn.Dropout(p) stand-in. ``mask`` (uint8 keep-mask, 1 = keep) may be injected for
-    reproducible runs; otherwise a fresh Bernoulli(1 - p) mask is drawn per training forward."""
+    """nn.Dropout(p) stand-in. ``mask`` (uint8 keep-mask, 1 = keep) may be injected for reproducible runs; otherwise a
+    fresh mask is drawn per training forward by the library's counter-based generator (``mla_dropout_mask``): element i
+    of the GLOBAL batch is kept iff hash24(seed, stream, i) >= p * 2^24, with seed = ``torch.initial_seed()`` at
+    construction (so ``torch.manual_seed`` makes runs repeatable, as with nn.Dropout) and stream = (this module's
+    ordinal, call count). A data-parallel rank passes the offset of its shard: N ranks draw the masks of one process."""
+
+    _instances = 0
 
     def __init__(self, p=0.5):
         super().__init__()
         self.p, self.mask = p, None
+        self.seed, self.calls = torch.initial_seed(), 0
+        Dropout._instances += 1
+        self.ordinal = Dropout._instances
 
-    def keep_mask(self, numel, device):
+    def keep_mask(self, numel, device, offset=0):
         if self.mask is not None:
             m = self.mask.to(device=device, dtype=torch.uint8).reshape(-1).contiguous()
             assert m.numel() == numel
             return m
-        return torch.empty(numel, dtype=torch.uint8, device=device).bernoulli_(1.0 - self.p)
+        self.calls += 1
+        return ops.dropout_mask(numel, self.seed, (self.ordinal << 32) + self.calls, offset, self.p, device)
 
     def forward(self, x):
         raise RuntimeError("Dropout is fused into the HIP BatchNorm/ReLU kernel of its parent module")

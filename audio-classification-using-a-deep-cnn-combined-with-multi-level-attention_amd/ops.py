@@ -217,26 +217,81 @@ def attention_pool(z, bags, T, K, nv, nf, y, save=False):
 # ----------------------------------------------------------------- training-step kernels ----
 
 class Dist:
-    """Data-parallel context for the statistics exchanges (SyncBN) of the training step.
-    world == 1: every all-reduce is a no-op."""
+    """Data-parallel context of the training step: SyncBN statistics, gradient buffer, loss and hit count are summed over
+    the ranks of a ``torch.distributed`` process group.
 
-    def __init__(self, group=None):
+    backend "nccl" (production: RCCL over xGMI): the sums run through the C ABI, ``mla_allreduce_flat`` on a communicator
+    this object creates with ``mla_comm_init_rank`` (the 128-byte id travels from rank 0 through torch.distributed). The
+    library binds the RCCL PyTorch has already loaded; MLA_DIST_COLLECTIVE=torch selects ``torch.distributed.all_reduce``
+    on the same device buffers instead. backend "gloo" (CPU rehearsals, two ranks sharing one test GPU): host copy.
+    world == 1: every all-reduce is a no-op unless ``always`` (or MLA_DIST_ALWAYS=1) asks for the collectives anyway --
+    a one-rank sum leaves the data unchanged, so the production branch can be exercised on a one-GPU box."""
+
+    def __init__(self, group=None, always=None):
+        import os
         import torch.distributed as dist
-        self.group = group
-        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.group, self.comm = group, None
+        inited = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if inited else 1
+        self.rank = dist.get_rank(group) if inited else 0
+        self.backend = dist.get_backend(group) if inited else None
+        always = (os.environ.get("MLA_DIST_ALWAYS") == "1") if always is None else always
+        self.active = inited and (self.world > 1 or always)
+        self.via = None
+        if self.active and self.backend == "nccl":
+            self.via = os.environ.get("MLA_DIST_COLLECTIVE", "abi")
+            if self.via == "abi":
+                self._init_comm(dist)
+        elif self.active:
+            self.via = "host"
+
+    def _init_comm(self, dist):
+        dev = torch.device("cuda", torch.cuda.current_device())
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (ctypes.c_char * 128)()
+            _lib.check(_lib.lib().mla_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        uid = uid.to(dev)
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        dist.broadcast(uid, src=src, group=self.group)
+        raw = bytes(uid.cpu().numpy().tobytes())
+        comm = ctypes.c_void_p()
+        _lib.check(_lib.lib().mla_comm_init_rank(ctypes.byref(comm), self.world, ctypes.c_char_p(raw), self.rank))
+        self.comm = comm
+
+    def close(self):
+        if self.comm is not None:
+            torch.cuda.synchronize()
+            _lib.check(_lib.lib().mla_comm_destroy(self.comm))
+            self.comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _reduce(self, t):
+        """The collective itself, whatever the world size."""
+        import torch.distributed as dist
+        if self.via == "abi":
+            assert t.is_cuda and t.is_contiguous()
+            code = {torch.float32: _lib.F32, torch.float64: _lib.F64, torch.int32: _lib.I32}[t.dtype]
+            _lib.check(_lib.lib().mla_allreduce_flat(_p(t), t.numel(), code, self.comm, _lib.stream_ptr()))
+        elif self.via == "torch":
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        elif t.is_cuda:                                   # gloo: through the host
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
 
     def all_reduce_sum(self, t):
-        """In-place sum over the group: RCCL (backend "nccl") directly on the device buffer; the
-        gloo backend (CPU rehearsals / tests) goes through a host copy."""
-        if self.world > 1:
-            import torch.distributed as dist
-            if t.is_cuda and dist.get_backend(self.group) == "gloo":
-                host = t.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
-                t.copy_(host)
-            else:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return t
+        """In-place sum over the group (see the class docstring for the transport)."""
+        return self._reduce(t) if self.active else t
 
 
 LOCAL = None          # set lazily (torch.distributed may not be initialised at import time)
@@ -246,8 +301,16 @@ def _local():
     global LOCAL
     if LOCAL is None:
         LOCAL = Dist.__new__(Dist)
-        LOCAL.group, LOCAL.world = None, 1
+        LOCAL.group, LOCAL.world, LOCAL.rank, LOCAL.active, LOCAL.comm, LOCAL.via = None, 1, 0, False, None, None
     return LOCAL
+
+
+def dropout_mask(n, seed, stream_id, offset, p_drop, device):
+    """uint8 keep-mask from the counter-based generator of the library (mla_dropout_mask; numpy restatement: weights.keep_mask)."""
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    _lib.check(_lib.lib().mla_dropout_mask(_p(out), n, int(seed) & (2 ** 64 - 1), int(stream_id) & (2 ** 64 - 1), int(offset), float(p_drop),
+                                           _lib.stream_ptr()))
+    return out
 
 
 def bn_stats_sync(x, mode, period, dist, running_mean=None, running_var=None, momentum=-1.0):
@@ -280,7 +343,7 @@ def bn_backward(x, dy, yout, act, drop_scale, mode, period, mean, var, gamma, di
     _lib.check(L.mla_bn_bwd_sums(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(yout), ld_y, act, float(drop_scale), rows, cols, mode,
                                  period, _p(mean), _p(var), BN_EPS, _p(_workspace(x.device)), _p(local), _lib.stream_ptr()))
     glob = local
-    if dist.world > 1:
+    if dist.active:
         glob = dist.all_reduce_sum(local.clone())
     count = (rows // period * cols if mode == 0 else rows) * dist.world
     if want_dx and dx is None:
@@ -333,8 +396,27 @@ def axpy(a, x, y):
     return y
 
 
+def check_labels(labels, K):
+    """nn.CrossEntropyLoss raises on a target outside [0, K) (train.py:372 has no ignore_index). Host tensors are checked
+    here before the upload (no device sync); for device tensors the kernel refuses to index with such a label and reports
+    it through `n_correct < 0` + a NaN loss, which `raise_on_bad_labels` turns into the same exception."""
+    if not labels.is_cuda and labels.numel():
+        lo, hi = int(labels.min()), int(labels.max())
+        if lo < 0 or hi >= K:
+            raise IndexError("Target %d is out of bounds." % (lo if lo < 0 else hi))
+
+
+def raise_on_bad_labels(hits):
+    """Call where the step's result is read on the host anyway (train.py:141-142): `hits` is cross_entropy's n_correct."""
+    n = int(hits)
+    if n < 0:
+        raise IndexError("Target out of bounds: %d label(s) outside [0, num_classes)." % -n)
+    return n
+
+
 def cross_entropy(scores, labels, inv_total, want_grad=True):
-    """CrossEntropyLoss(mean over the GLOBAL batch) on (B, K) scores: (loss, dscores, n_correct)."""
+    """CrossEntropyLoss(mean over the GLOBAL batch) on (B, K) scores: (loss, dscores, n_correct).
+    n_correct < 0 (and a NaN loss): -n_correct labels were outside [0, K) -- see check_labels."""
     _chk(scores, torch.float32); _chk(labels, torch.int64)
     B, K = scores.shape
     loss = torch.empty(1, dtype=torch.float32, device=scores.device)

@@ -13,11 +13,12 @@ from . import vggish_params
 from .. import frontend
 
 
-def waveform_to_examples(data, sample_rate, return_tensor=True):
+def waveform_to_examples(data, sample_rate, return_tensor=True, _pcm16=False):
     """Waveform -> VGGish examples.
 
     data: np.ndarray or torch tensor, 1-D mono or 2-D ``(samples, channels)`` (averaged over
-    axis 1, vggish_input.py:49-50); float in [-1, 1] or int16 PCM.
+    axis 1, vggish_input.py:49-50). Values are used as they are, whatever the dtype: like the
+    reference this function never rescales (only ``wavfile_to_examples`` divides int16 PCM by 32768).
     Returns ``(N, 1, 96, 64)`` float32 CUDA tensor (requires_grad=True, vggish_input.py:79-80)
     or, with ``return_tensor=False``, an ``(N, 96, 64)`` float64 ndarray like the reference.
     """
@@ -26,7 +27,7 @@ def waveform_to_examples(data, sample_rate, return_tensor=True):
         #  and resampy is not available -> refuse rather than guess.
         raise NotImplementedError("only %d Hz input is supported on the HIP path (got %r)"
                                   % (vggish_params.SAMPLE_RATE, sample_rate))
-    examples = frontend.waveforms_to_examples(frontend.as_device_mono(data)[None], out_dtype=torch.float32)
+    examples = frontend.waveforms_to_examples(frontend.as_device_mono(data, pcm16=_pcm16)[None], out_dtype=torch.float32)
     if return_tensor:
         return examples[:, None, :, :].requires_grad_(True)
     return examples.cpu().numpy().astype(np.float64)
@@ -42,4 +43,4 @@ def wavfile_to_examples(wav_file, return_tensor=True):
         pcm = np.frombuffer(wf.readframes(wf.getnframes()), dtype=np.int16)
     if ch > 1:
         pcm = pcm.reshape(-1, ch)
-    return waveform_to_examples(pcm, sr, return_tensor)
+    return waveform_to_examples(pcm, sr, return_tensor, _pcm16=True)

@@ -64,16 +64,28 @@ class TrainStep:
     (model.py:237-238); like torch's Adam (which skips ``grad is None``) they are left untouched.
     """
 
-    def __init__(self, clf, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+    def __init__(self, clf, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, params=None):
+        """``params``: the parameters the caller's optimizer holds (``optimizer.param_groups[...]["params"]``); None =
+        every parameter that requires grad. Exactly the tensors in ``params`` that require grad are updated, as
+        ``optimizer.step()`` does in the reference (train.py:138; torch's Adam skips parameters whose ``.grad`` is None,
+        i.e. the frozen ones). Gradients of parameters OUTSIDE that set are not computed: the reference computes and then
+        never applies them (its ``__main__`` builds the Adam before ``set_requires_grad(clf, True)``, train.py:369-370 vs
+        :96-97, so its "finetune" run only ever steps the MLA head) -- the updated model is the same."""
         self.clf, self.lr, self.betas, self.eps, self.t = clf, lr, betas, eps, 0
         self.dist = ops.Dist(process_group)
-        self.finetune = any(p.requires_grad for p in clf.cnn.parameters())
-        if self.finetune and clf.cnn.precision != "f32":
-            raise NotImplementedError("finetune (CNN gradients) is built for precision='f32' only")
-        if self.finetune and not all(p.requires_grad for p in clf.cnn.parameters()):
-            raise NotImplementedError("partially trainable CNNs are not supported: freeze it or train all of it")
-        named = [(n, p) for n, p in clf.named_parameters() if p.requires_grad and ".fcf." not in n]
+        held = None if params is None else {id(p) for p in params}
+        named = [(n, p) for n, p in clf.named_parameters()
+                 if p.requires_grad and ".fcf." not in n and (held is None or id(p) in held)]
+        if not named:
+            raise ValueError("no trainable parameter to update")
+        # CNN gradients are needed iff the update set holds a CNN parameter; any subset of the CNN is fine (the backward
+        # pass stops at the lowest layer that needs a gradient and skips the weight gradients nobody asked for)
+        self.finetune = any(n.startswith("cnn.") for n, _ in named)
+        if self.finetune and clf.cnn.precision not in ("f32", "bf16"):
+            raise NotImplementedError("CNN gradients are built for precision 'f32' (exact) and 'bf16' (bf16 arithmetic, f32 "
+                                      "master weights), not %r" % clf.cnn.precision)
         dev = named[0][1].device
+        assert dev.type == "cuda", "TrainStep needs the model on the GPU (train_model moves it there, train.py:101)"
         pad4 = lambda k: (k + 3) // 4 * 4                 # every tensor starts 16-byte aligned (GEMM operand rule)
         total = sum(pad4(p.numel()) for _, p in named)
         self.n_params = sum(p.numel() for _, p in named)
@@ -81,14 +93,21 @@ class TrainStep:
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.grads, off = {}, 0
+        self.grads, self._seated, off = {}, [], 0
         for n, p in named:
             k = p.numel()
             self.flat_p[off:off + k].copy_(p.detach().reshape(-1))
             p.data = self.flat_p[off:off + k].view(p.shape)
             self.grads[n] = self.flat_g[off:off + k].view(p.shape)
+            self._seated.append((n, p, self.flat_p.data_ptr() + 4 * off))
             off += pad4(k)
-        self.mla_grads = {n[len("mla."):]: g for n, g in self.grads.items() if n.startswith("mla.")}
+        # MLA parameters outside the update set still need somewhere to write their gradient (the head's backward always
+        # runs whole: it is 0.3 ms); those scratch tensors are never read
+        self.mla_grads = {}
+        for n, p in clf.mla.named_parameters():
+            if ".fcf." in n:
+                continue
+            self.mla_grads[n] = self.grads["mla." + n] if "mla." + n in self.grads else torch.empty_like(p, dtype=torch.float32, device=dev)
 
     def state_dict(self):
         """Optimizer state as plain tensors (Adam moments over the flat buffer + step count): what
@@ -106,6 +125,10 @@ class TrainStep:
         """inputs (B, T, 1, 96, 64) (or whatever ``clf.input`` reshapes), labels (B,) int64.
         Returns (loss, n_correct) as device tensors (no host sync; train.py:141-142 syncs via .item())."""
         clf = self.clf
+        for n, p, ptr in self._seated:
+            if p.data_ptr() != ptr:
+                raise RuntimeError("parameter %s no longer lives in the flat buffer of this TrainStep (the model was moved or "
+                                   "cast after the step was built): build a new TrainStep" % n)
         clf.train()
         B_global = inputs.shape[0] * self.dist.world
         with torch.no_grad():
@@ -116,13 +139,15 @@ class TrainStep:
                 feats = clf.cnn(x)
             ctx = mla_train.Ctx(tape=True, dist=self.dist)
             out = mla_train.mla_forward(clf.mla, feats.reshape(-1, T, clf.emb_input_size), ctx)
+            ops.check_labels(labels, out.shape[1])
             loss, dout, hits = ops.cross_entropy(out, labels.to(out.device).long().contiguous(), 1.0 / B_global)
             d_feats = mla_train.mla_backward(clf.mla, ctx, dout, self.mla_grads, need_input_grad=self.finetune)
             if self.finetune:
                 cnn_train.backward(clf.cnn.cnn_model, cnn_tape, d_feats, self.grads, "cnn.cnn_model.")
-            if self.dist.world > 1:
+            if self.dist.active:
                 self.dist.all_reduce_sum(self.flat_g)
                 self.dist.all_reduce_sum(loss)
+                self.dist.all_reduce_sum(hits)             # running_corrects (train.py:142) over the global batch
             self.t += 1
             ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
             if self.finetune:                      # derived (repacked / bf16) weight copies are stale now
@@ -138,11 +163,13 @@ def _evaluate(clf, loader, device, collect=False):
     tot_loss, tot_hits, n, preds, trues = 0.0, 0, 0, [], []
     with torch.no_grad():
         for inputs, labels in loader:
+            host_labels = labels
             inputs, labels = inputs.to(device).float(), labels.to(device).long()
             out = clf(inputs)
+            ops.check_labels(host_labels, out.shape[1])
             loss, _, hits = ops.cross_entropy(out, labels.contiguous(), 1.0 / inputs.shape[0], want_grad=False)
             tot_loss += float(loss) * inputs.shape[0]
-            tot_hits += int(hits)
+            tot_hits += ops.raise_on_bad_labels(hits)
             n += inputs.shape[0]
             if collect:
                 preds.append(torch.max(out, 1)[1].cpu()); trues.append(labels.cpu())
@@ -223,20 +250,27 @@ def load_model(model_args, path):
 def train_model(clf, dataloaders, criterion, optimizer, num_epochs=25, patience=10, save_model_path=None, resume=False,
                 finetune=False):
     """Epoch loop with the reference's signature and return value (train.py:53-179):
-    (model with the best-validation weights, validation accuracy history, test accuracy).
-    ``criterion`` must be nn.CrossEntropyLoss and ``optimizer`` torch.optim.Adam: their
-    hyper-parameters are read and the fused HIP step is used instead of autograd. Checkpoints hold tensors only
+    (model with the best-validation weights, validation accuracy history, test_model's result).
+    ``criterion`` must be nn.CrossEntropyLoss and ``optimizer`` a one-group torch.optim.Adam without weight decay /
+    amsgrad: its hyper-parameters AND its parameter list are read -- the fused HIP step updates exactly the tensors the
+    optimizer holds (and that require grad), as ``optimizer.step()`` does; the torch optimizer object itself is not
+    stepped (its ``state`` stays empty; the moments live in the checkpoint written here). Checkpoints hold tensors only
     (``_save_checkpoint``); ``resume=True`` continues from ``save_model_path`` (epoch, best accuracy, history,
     weights and Adam moments), as train.py:80-94 does from its pickled objects."""
     if not isinstance(criterion, nn.CrossEntropyLoss) or not isinstance(optimizer, torch.optim.Adam):
         raise TypeError("the HIP training step implements CrossEntropyLoss + Adam (train.py:369-372)")
+    if len(optimizer.param_groups) != 1:
+        raise NotImplementedError("the HIP Adam step takes ONE parameter group (train.py:369-370 builds one)")
+    g = optimizer.param_groups[0]
+    if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False):
+        raise NotImplementedError("weight_decay / amsgrad / maximize are not implemented by the HIP Adam step (train.py:369 uses none)")
     if finetune:
         from .model import set_requires_grad
-        set_requires_grad(clf, True)                       # train.py:96-97
+        set_requires_grad(clf, True)                       # train.py:96-97 (AFTER the caller built the optimizer)
     import copy
-    g = optimizer.param_groups[0]
-    device = next(clf.parameters()).device
-    step = TrainStep(clf, lr=g["lr"], betas=g["betas"], eps=g["eps"])
+    device = torch.device("cuda", torch.cuda.current_device())
+    clf.to(device)                                         # train.py:101
+    step = TrainStep(clf, lr=g["lr"], betas=g["betas"], eps=g["eps"], params=g["params"])     # steps what the optimizer holds
     since, val_acc_history, best_acc, best_epoch, first_epoch = time.time(), [], 0.0, 0, 0
     if resume:
         assert save_model_path is not None
@@ -250,8 +284,8 @@ def train_model(clf, dataloaders, criterion, optimizer, num_epochs=25, patience=
         print("Epoch {}/{}".format(epoch + 1, num_epochs)); print("-" * 10)
         run_loss, run_hits, n = 0.0, 0, 0
         for inputs, labels in dataloaders["train"]:
-            loss, hits = step(inputs.to(device).float(), labels.to(device))
-            run_loss += float(loss) * inputs.shape[0]; run_hits += int(hits); n += inputs.shape[0]
+            loss, hits = step(inputs.to(device).float(), labels)
+            run_loss += float(loss) * inputs.shape[0]; run_hits += ops.raise_on_bad_labels(hits); n += inputs.shape[0]
         print("train Loss: {:.4f}, Acc: {:.4f}".format(run_loss / max(n, 1), run_hits / max(n, 1)))
         v_loss, v_acc = _evaluate(clf, dataloaders["val"], device)
         print("val Loss: {:.4f}, Acc: {:.4f}".format(v_loss, v_acc))
@@ -269,4 +303,4 @@ def train_model(clf, dataloaders, criterion, optimizer, num_epochs=25, patience=
     final = save_model_path or "best_weights.h5"
     root, ext = os.path.splitext(final)
     save_model(clf, root + ("_final_finetuned" if finetune else "_final") + ext)       # train.py:173-177
-    return clf, val_acc_history, (tested[0] if tested is not None else None)
+    return clf, val_acc_history, tested                    # test_model's (accuracy, summary) tuple or None, as train.py:179

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: 0.96 s clips/s, wave -> class scores (VGGish + multi-level attention).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N > 1 from a plain `python`: this process spawns the N ranks
+                                                            itself, one per GPU, BEFORE it touches the GPU; under
+                                                            torch.distributed.run it is one of the ranks)
     python bench.py --mode train [--finetune] ...          (BASELINE configs 4/5: the data-parallel train.py step)
 
 One step = one pass of the whole hot path over one batch of synthetic 16 kHz PCM that is
@@ -37,10 +39,21 @@ CONV_DESC = {"conv2": "64->128 @48x32 +pool", "conv3": "128->256 @24x16", "conv4
              "conv5": "256->512 @12x8", "conv6": "512->512 @12x8 +pool"}
 # MI355X_MICROARCH.md: dense bf16 MFMA / f32 MFMA. bf16x3 is priced in ALGORITHMIC flops against the bf16 peak (it issues 3x)
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "bf16x3": 2500.0}
-# HBM bytes per launch of the dominant kernel at the default batch, from rocprofv3 --pmc FETCH_SIZE (x2, gfx950)
-# + WRITE_SIZE in separate passes: profiles/r01_pmc_traffic.txt. Not measurable from inside this process.
-PMC_TRAFFIC = {("conv4", "bf16", 10240): 3.38e9}
 PEAK_HBM_GBPS = 8000.0
+
+# algorithmic HBM bytes per clip of a conv layer: input + output activations once (elem = bytes per element); weights are
+# read once per launch and are negligible
+CONV_BYTES = {"conv2": lambda e: (48 * 32 * 64 + 24 * 16 * 128) * e, "conv3": lambda e: (24 * 16 * 128 + 24 * 16 * 256) * e,
+              "conv4": lambda e: (24 * 16 * 256 + 12 * 8 * 256) * e, "conv5": lambda e: (12 * 8 * 256 + 12 * 8 * 512) * e,
+              "conv6": lambda e: (12 * 8 * 512 + 6 * 4 * 512) * e}
+
+
+def kernel_averages(prof):
+    per = {}
+    for name, e0, e1 in prof:
+        per.setdefault(name, []).append(e0.elapsed_time(e1) * 1e-3)
+    return {k: sum(v) / len(v) for k, v in per.items()}
+
 
 CNN_CONF = dict(cnn_type="vggish", num_classes=10, use_pretrained=False, just_bottlenecks=False,
                 cnn_trainable=False, first_cnn_layer_trainable=False, in_channels=1)
@@ -121,10 +134,12 @@ def small_batch_leg(ens, rank, device, bags=102, steps=50):
     return out
 
 
-def parity_mode_leg(ens, pcm, clips_per_step, steps=5):
+def parity_mode_leg(ens, pcm, clips_per_step, ops, steps=5):
     """The same batch in the bf16x3 mode: still bf16 MFMA arithmetic, but every value carried as hi + lo bf16 planes and
     every product as three bf16 terms with f32 accumulation, which meets the north star's 1e-4 relative tolerance on the
-    scores (the plain bf16 headline does not: `cpu_baseline.parity_max_rel_*`). Also the exact-f32 MFMA mode beside it."""
+    scores (the plain bf16 headline does not: `cpu_baseline.parity_max_rel_*`). Also the exact-f32 MFMA mode beside it.
+    conv_stack_frac_algorithmic prices the layer's algorithmic flops against the mode's MFMA peak (bf16 peak for bf16x3);
+    conv_stack_frac_issued counts the three bf16 products bf16x3 actually issues per term."""
     out = {}
     keep = ens.cnn.precision
     with torch.no_grad():
@@ -137,7 +152,14 @@ def parity_mode_leg(ens, pcm, clips_per_step, steps=5):
                 ens.forward_waveforms(pcm)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / n
-            out[prec] = {"ms_per_step": dt * 1e3, "clips_per_s": clips_per_step / dt}
+            ops.profile = []
+            ens.forward_waveforms(pcm)
+            torch.cuda.synchronize()
+            avg, ops.profile = kernel_averages(ops.profile), None
+            conv_t = sum(avg[k] for k in avg if k in CONV_MFLOP)
+            frac = clips_per_step * sum(CONV_MFLOP.values()) * 1e6 / conv_t / 1e12 / PEAK_TFLOPS[prec]
+            out[prec] = {"ms_per_step": dt * 1e3, "clips_per_s": clips_per_step / dt, "conv_stack_ms": conv_t * 1e3,
+                         "conv_stack_frac_algorithmic": frac, "conv_stack_frac_issued": frac * (3 if prec == "bf16x3" else 1)}
     ens.set_precision(keep)
     return out
 
@@ -174,26 +196,67 @@ def h2d_leg(pcm, step_s, clips_per_step, reps=5, ens=None):
     return out
 
 
+TRAIN_MFLOP_FWD = sum(CONV_MFLOP.values()) + sum(FC_MFLOP.values())       # per clip, conv + FC forward
+# finetune: forward + weight gradient + input gradient of every layer (conv1 has no input gradient); the MLA head's
+# ~5 MFLOP per clip are not counted
+TRAIN_MFLOP = {"frozen": TRAIN_MFLOP_FWD, "finetune": 3 * TRAIN_MFLOP_FWD - CONV_MFLOP["conv1"]}
+
+
+def make_train_step(bags, finetune, precision, rank, device):
+    W = importlib.import_module(PKG + ".weights")
+    M = importlib.import_module(PKG + ".model")
+    TR = importlib.import_module(PKG + ".train")
+    ens = M.Ensemble("repeat", CNN_CONF, [2, 1], device, precision=precision)
+    ens.load_state_dict({k: torch.as_tensor(v) for k, v in W.make_state_dict(7, W.ensemble_shapes((2, 1), False)).items()})
+    ens.to(device)
+    if finetune:
+        M.set_requires_grad(ens, True)
+    step = TR.TrainStep(ens, lr=1e-4 if finetune else 1e-3)
+    x = torch.from_numpy(W.uniform(4000 + rank, 1, bags * T_BAG * 96 * 64, lo=-1.4, hi=4.6)).reshape(bags, T_BAG, 1, 96, 64).to(device)
+    y = torch.from_numpy(W.bits24(4000 + rank, 2, bags) % 10).to(device)
+    return step, x, y
+
+
+def train_leg(device, bags=512, steps=5, warmup=2):
+    """BASELINE config 4 on the driver's clock (N = 1 line): the train.py step (zero_grad -> forward -> CrossEntropyLoss ->
+    backward -> Adam) on 512 bags = 5 120 clips of 96 x 64 log-mel, frozen CNN in bf16 (the reference default
+    cnn_trainable=False) and finetune (every parameter trainable, train.py:96-97) in bf16 with f32 master weights and in
+    exact f32; FLOP-roofline fraction = algorithmic conv + FC flops (forward only when frozen; forward + dgrad + wgrad
+    when finetuning) / step time / the MFMA peak of the arithmetic type."""
+    out = {"bags": bags, "clips_per_step": bags * T_BAG}
+    for name, finetune, precision, n in (("frozen_bf16", False, "bf16", steps), ("finetune_bf16", True, "bf16", steps),
+                                         ("finetune_f32", True, "f32", 2)):
+        try:
+            step, x, y = make_train_step(bags, finetune, precision, 0, device)
+        except NotImplementedError as e:
+            out[name] = {"error": str(e)}
+            continue
+        for _ in range(warmup):
+            loss, _ = step(x, y)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss, _ = step(x, y)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        tf = bags * T_BAG * TRAIN_MFLOP["finetune" if finetune else "frozen"] * 1e6 / dt / 1e12
+        out[name] = {"ms_per_step": dt * 1e3, "clips_per_s": bags * T_BAG / dt, "TFLOPs": tf, "peak": PEAK_TFLOPS[precision],
+                     "frac": tf / PEAK_TFLOPS[precision], "loss_last": float(loss)}
+        del step, x, y
+        torch.cuda.empty_cache()
+    return out
+
+
 def train_mode(args, world, rank, device):
     """BASELINE configs 4 / 5: one step = zero_grad -> forward -> CrossEntropyLoss -> backward -> Adam (train.py:124-138)
     on `bags` bags of 96 x 64 log-mel input per GPU (default 512; global batch = world x bags, 4096 at 8 GPUs), sharded by
     bag. Per step the ranks exchange the BatchNorm sums (SyncBN: the step equals the reference's single-process step
-    on the global batch) and ONE flat-gradient all-reduce over RCCL. Frozen CNN (the reference default) unless
-    --finetune; CNN precision from --precision (finetune: f32)."""
+    on the global batch) and the flat gradient buffer over RCCL. Frozen CNN (the reference default) unless
+    --finetune; CNN precision from --precision."""
     import torch.distributed as dist
-    W = importlib.import_module(PKG + ".weights")
-    M = importlib.import_module(PKG + ".model")
-    TR = importlib.import_module(PKG + ".train")
     bags = args.bags if args.bags != 1024 else 512
-    precision = "f32" if args.finetune else args.precision
-    ens = M.Ensemble("repeat", CNN_CONF, [2, 1], device, precision=precision)
-    ens.load_state_dict({k: torch.as_tensor(v) for k, v in W.make_state_dict(7, W.ensemble_shapes((2, 1), False)).items()})
-    ens.to(device)
-    if args.finetune:
-        M.set_requires_grad(ens, True)
-    step = TR.TrainStep(ens, lr=1e-4 if args.finetune else 1e-3)
-    x = torch.from_numpy(W.uniform(4000 + rank, 1, bags * T_BAG * 96 * 64, lo=-1.4, hi=4.6)).reshape(bags, T_BAG, 1, 96, 64).to(device)
-    y = torch.from_numpy(W.bits24(4000 + rank, 2, bags) % 10).to(device)
+    precision = args.precision
+    step, x, y = make_train_step(bags, args.finetune, precision, rank, device)
 
     def barrier():
         if world > 1:
@@ -215,19 +278,93 @@ def train_mode(args, world, rank, device):
     if rank == 0:
         clips = bags * T_BAG
         assert bool(torch.isfinite(loss))
+        kind = "finetune" if args.finetune else "frozen"
+        tf = world * clips * TRAIN_MFLOP[kind] * 1e6 * args.steps / elapsed / 1e12
         print(json.dumps({
             "metric": "0.96 s clips/sec train step fwd+bwd+Adam (VGGish+attn)", "value": world * clips * args.steps / elapsed,
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": precision, "data": "synthetic",
             "config": {"workload": "BASELINE config %s: train.py step on %d bags x 10 x (96 x 64) log-mel per GPU, %s, Adam lr %g, "
-                                   "MLA [2,1]; SyncBN sums + one flat-gradient all-reduce (%d floats) per step"
+                                   "MLA [2,1]; SyncBN sums + flat-gradient all-reduce (%d floats) per step"
                                    % ("5" if world > 1 else "4", bags, "finetune (all parameters)" if args.finetune else "frozen CNN (reference default)",
                                       step.lr, step.n_params),
                        "bags_per_gpu": bags, "global_batch_bags": world * bags, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": world * PEAK_TFLOPS[precision], "unit": "TFLOP/s",
+                         "frac": tf / (world * PEAK_TFLOPS[precision]), "traffic": None,
+                         "flop_per_clip": TRAIN_MFLOP[kind] * 1e6, "what": "whole step, algorithmic conv + FC flops"},
             "loss_last": float(loss)}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, timeout_s):
+    """`python bench.py --gpus N` from a plain shell: spawn the N ranks (one process per GPU) as CHILD processes with the
+    torch.distributed.run environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), relay rank 0's JSON line and return
+    the first non-zero child exit code. The parent has made no GPU call when it gets here and makes none afterwards
+    (a process that has initialised the GPU must never exec or fork workers). The library is built here, once, so that
+    no rank imports a half-written .so."""
+    import subprocess
+    import tempfile
+    importlib.import_module(PKG + ".build").build(verbose=False)
+    port = free_port()
+    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs, outs = [], []
+    for r in range(n):
+        out = tempfile.TemporaryFile(mode="w+") if r == 0 else subprocess.DEVNULL
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv,
+                                      env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=out))
+    deadline, rc = time.time() + timeout_s, 0
+    live = set(range(n))
+    while live and rc == 0:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is not None:
+                live.discard(r)
+                if code != 0:
+                    rc = code
+                    sys.stderr.write("bench.py: rank %d exited with code %d\n" % (r, code))
+        if time.time() > deadline:
+            rc = 124
+            sys.stderr.write("bench.py: ranks still running after %d s\n" % timeout_s)
+        time.sleep(0.05)
+    for r in live:                                    # a rank failed or timed out: stop exactly the children started here
+        procs[r].terminate()
+    for r in live:
+        try:
+            procs[r].wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+    outs[0].seek(0)
+    sys.stdout.write(outs[0].read())
+    sys.stdout.flush()
+    return rc
+
+
+def dry_run(args, world, rank):
+    """Launch-path self-test without a GPU (tests/test_bench_launch_cpu.py): rendezvous, one all-reduce, one JSON line."""
+    import torch.distributed as dist
+    if rank == args.dry_run_fail_rank:
+        raise SystemExit(7)
+    total = float(rank)
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        dist.all_reduce(t)
+        total = float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": total, "mode": args.mode}), flush=True)
 
 
 def main():
@@ -240,18 +377,27 @@ def main():
                     help="conv/FC arithmetic: bf16 (BASELINE config 3), f32 = exact f32 MFMA, bf16x3 = three bf16 MFMA products per term (f32-grade)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer (default, the headline metric) or train: BASELINE configs 4/5, the data-parallel train.py step")
-    ap.add_argument("--finetune", action="store_true", help="--mode train: every parameter trainable (f32), train.py:96-97")
+    ap.add_argument("--finetune", action="store_true", help="--mode train: every parameter trainable, train.py:96-97")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the 1 020-clip eager / HIP-graph leg")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the bf16x3 (1e-4-parity arithmetic) leg")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the config-4 training-step leg of the N = 1 line")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse N>1 on one GPU)")
+    ap.add_argument("--launch-timeout", type=int, default=1500, help="seconds the self-launched ranks may run")
+    ap.add_argument("--dry-run", action="store_true", help="launch-path self-test: no GPU work (CPU tests)")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, world, rank)
     local_rank %= max(torch.cuda.device_count(), 1)          # rehearsal on fewer GPUs than ranks (gloo only)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -262,12 +408,30 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(args.backend)
-
-    importlib.import_module(PKG + ".build").build(verbose=False) if rank == 0 and not os.path.exists(
-        os.path.join(ROOT, PKG, "libmla_hip.so")) else None
+    # under torch.distributed.run nobody built the library for us: rank 0 does, everybody else waits for it
+    if rank == 0:
+        importlib.import_module(PKG + ".build").build(verbose=False)
+    if world > 1:
+        dist.barrier()
     ops = importlib.import_module(PKG + ".ops")
     if args.mode == "train":
         return train_mode(args, world, rank, device)
+    return infer_mode(args, world, rank, device, ops)
+
+
+def load_pmc_traffic():
+    """HBM bytes per clip of the dominant kernels, from rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate
+    passes (profiles/r02_pmc_traffic.json, written by scripts/profile_traffic.sh). PMC counters cannot be read from inside
+    this process; per-launch traffic = per-clip figure x the clips of this launch (both kernels stream per clip)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f)
+
+
+def infer_mode(args, world, rank, device, ops):
+    import torch.distributed as dist
     ens, sd = build_model(args.precision, device)
     pcm = synth_pcm(args.bags, rank, device)
     clips_per_step = args.bags * T_BAG
@@ -296,10 +460,7 @@ def main():
         elapsed = float(tmax.item())
 
     if rank == 0:
-        per = {}
-        for name, e0, e1 in prof:
-            per.setdefault(name, []).append(e0.elapsed_time(e1) * 1e-3)
-        avg = {k: sum(v) / len(v) for k, v in per.items()}
+        avg = kernel_averages(prof)
         dom = max((k for k in avg if k in CONV_DESC), key=lambda k: avg[k])
         tf = clips_per_step * CONV_MFLOP[dom] * 1e6 / avg[dom] / 1e12
         peak = PEAK_TFLOPS[args.precision]
@@ -307,6 +468,9 @@ def main():
         conv_tf = clips_per_step * sum(CONV_MFLOP.values()) * 1e6 / conv_t / 1e12
         fe_dtype = torch.bfloat16 if args.precision == "bf16" else torch.float32
         fe_gbps = clips_per_step * FE_BYTES[fe_dtype] / avg["logmel"] / 1e9
+        traffic = load_pmc_traffic()
+        t_dom = traffic.get("%s/%s" % (dom, args.precision))
+        t_fe = traffic.get("logmel/%s" % ("bf16" if fe_dtype == torch.bfloat16 else "f32"))
         result = {
             "metric": "0.96 s clips/sec wave->logits (VGGish+attn)", "value": world * clips_per_step * args.steps / elapsed,
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -317,24 +481,47 @@ def main():
                                    "%s conv+FC" % (args.bags, clips_per_step, args.precision),
                        "bags_per_gpu": args.bags, "clips_per_step_per_gpu": clips_per_step, "parallelism": "dp%d (no collective: independent bags)" % world},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_kernel %s (%s)" % (dom, CONV_DESC[dom]), "achieved": tf, "peak": peak,
-                         "unit": "TFLOP/s", "frac": tf / peak, "traffic": PMC_TRAFFIC.get((dom, args.precision, clips_per_step)),
+                         "unit": "TFLOP/s", "frac": tf / peak,
+                         "traffic": t_dom["bytes_per_clip"] * clips_per_step if t_dom else None,
+                         "traffic_source": t_dom["source"] if t_dom else "no PMC pass on file for this kernel / dtype",
+                         "algorithmic_bytes": CONV_BYTES[dom](2 if args.precision == "bf16" else 4) * clips_per_step if dom in CONV_BYTES else None,
                          "avg_launch_ms": avg[dom] * 1e3, "flop_per_launch": clips_per_step * CONV_MFLOP[dom] * 1e6},
             "roofline_conv_stack": {"bound": "mfma", "achieved": conv_tf, "peak": peak, "unit": "TFLOP/s", "frac": conv_tf / peak,
-                                    "ms": conv_t * 1e3},
+                                    "ms": conv_t * 1e3,
+                                    "per_kernel_frac": {k: round(clips_per_step * m * 1e6 / avg[k] / 1e12 / peak, 4)
+                                                        for k, m in list(CONV_MFLOP.items()) + list(FC_MFLOP.items()) if k in avg}},
             "roofline_frontend": {"bound": "hbm", "kernel": "logmel_kernel", "achieved": fe_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                   "frac": fe_gbps / PEAK_HBM_GBPS, "avg_launch_ms": avg["logmel"] * 1e3,
-                                  "bytes_per_clip": FE_BYTES[fe_dtype]},
+                                  "bytes_per_clip": FE_BYTES[fe_dtype],
+                                  "traffic": t_fe["bytes_per_clip"] * clips_per_step if t_fe else None},
             "kernel_ms": {k: round(v * 1e3, 4) for k, v in sorted(avg.items())},
         }
         if world == 1 and args.precision == "bf16" and not args.no_parity_mode:
-            result["parity_mode"] = parity_mode_leg(ens, pcm, clips_per_step)
-        if world == 1:
+            result["parity_mode"] = parity_mode_leg(ens, pcm, clips_per_step, ops)
+        if world == 1 and not args.no_h2d:
             result["h2d"] = h2d_leg(pcm, elapsed / args.steps, clips_per_step, ens=ens)
         if world == 1 and not args.no_small_batch:
             result["small_batch"] = small_batch_leg(ens, rank, device)
         if world == 1 and not args.no_cpu_baseline:
             with torch.no_grad():
                 result["cpu_baseline"] = cpu_baseline(sd, ens, device)
+        # north star: "logits within 1e-4 rel of the CPU reference" -- the throughput of the fastest arithmetic mode whose
+        # MEASURED deviation from the oracle meets it, stated at top level beside `value` (which is BASELINE config 3's bf16)
+        if "cpu_baseline" in result and "parity_mode" in result:
+            cands = [("bf16", result["value"], result["roofline_conv_stack"]["frac"], result["roofline_conv_stack"]["frac"])]
+            for m in ("bf16x3", "f32"):
+                pm = result["parity_mode"][m]
+                cands.append((m, pm["clips_per_s"], pm.get("conv_stack_frac_algorithmic"), pm.get("conv_stack_frac_issued")))
+            ok = [c for c in cands if result["cpu_baseline"]["parity_max_rel_%s" % c[0]] <= 1e-4]
+            if ok:
+                best = max(ok, key=lambda c: c[1])
+                result["value_at_tolerance"] = {"value": best[1], "unit": "clips/s", "mode": best[0], "tolerance": 1e-4,
+                                                "measured_max_rel": result["cpu_baseline"]["parity_max_rel_%s" % best[0]],
+                                                "conv_stack_frac_algorithmic": best[2], "conv_stack_frac_issued": best[3]}
+        if world == 1 and not args.no_train_leg:
+            del ens, pcm
+            torch.cuda.empty_cache()
+            result["train_step"] = train_leg(device)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

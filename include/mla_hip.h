@@ -42,6 +42,8 @@ extern "C" {
 #define MLA_F32   0
 #define MLA_BF16  1
 #define MLA_I16   2
+#define MLA_F64   4  /* mla_allreduce_flat only (the BatchNorm sums travel in double precision) */
+#define MLA_I32   5  /* mla_allreduce_flat only (n_correct)                                        */
 #define MLA_BF16X3 3  /* "split" bf16: x = hi + lo, two bf16 planes [hi(C) | lo(C)] per row / pixel; three bf16 MFMA
                         * products per term (hi*hi + hi*lo + lo*hi) with f32 accumulation: f32-grade results (2^-18
                         * relative per product) at a third of the bf16 rate. Accepted by mla_vggish_conv1 (output),
@@ -295,6 +297,35 @@ int mla_conv1_bwd(const float* x, const float* w, const float* bias, const float
 /* torch.optim.Adam step t (train.py:369; no weight decay, no amsgrad) over one flat buffer. */
 int mla_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, int64_t step, mla_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Data-parallel exchange (the reference is single-process, train.py:119-142: these entry
+ * points are what makes its step run sharded over the GPUs of a node) and the dropout masks of the step.
+ * ---------------------------------------------------------------------------------- */
+
+/* RCCL communicator of this process' rank. The library binds the RCCL ALREADY LOADED in the process (dlopen NOLOAD: the one
+ * PyTorch ships, or the host's own; ROCm's librccl.so.1 only if none is loaded) -- it never links a second one.
+ * mla_comm_unique_id: rank 0 fills a 128-byte HOST buffer (ncclGetUniqueId) and distributes it by the host's own means;
+ * mla_comm_init_rank: every rank, with its HIP device current (ncclCommInitRank; blocks until all ranks have called);
+ * an ncclComm_t the host created itself may be passed as `comm` to mla_allreduce_flat unchanged. */
+int         mla_comm_unique_id(void* id_host_128);
+int         mla_comm_init_rank(void** comm_out, int nranks, const void* id_host_128, int rank);
+int         mla_comm_destroy(void* comm);
+const char* mla_comm_library_origin(void);   /* "already loaded by the host" | "loaded by libmla_hip" | "none" */
+
+/* In-place sum over the ranks of `comm` of a flat device buffer (ncclAllReduce, ncclSum), enqueued on `stream`:
+ * the gradient buffer (or one bucket of it) of loss.backward() (train.py:137) before optimizer.step() (train.py:138),
+ * the SyncBN (sum, sum of squares) doubles of mla_bn_stats_sums / mla_bn_bwd_sums, the loss and n_correct.
+ * dtype: MLA_F32, MLA_F64 or MLA_I32. */
+int mla_allreduce_flat(void* buf, int64_t count, int dtype, void* comm, mla_stream_t stream);
+
+/* nn.Dropout(p) keep-mask (model.py:213, 1 = keep), counter-based so that it is reproducible and shardable: element i
+ * of the GLOBAL tensor gets 1 iff hash24(seed, stream_id, offset + i) >= round(p_drop * 2^24), hash24 = top 24 bits of
+ * the splitmix64 finaliser over (seed, stream_id, index) (bit-exact numpy restatement: <pkg>/weights.py keep_mask).
+ * A rank that owns elements [offset, offset + n) of the global batch passes its offset: N ranks draw the masks of a
+ * single-process run. Consumed by mla_bn_apply (keep_mask argument). */
+int mla_dropout_mask(uint8_t* mask, int64_t n, uint64_t seed, uint64_t stream_id, uint64_t offset, float p_drop,
+                     mla_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -248,17 +248,30 @@ def gen_ensemble(ref_model, vggish_input):
     return g
 
 
+SUBSET_PARAMS = ("cnn.cnn_model.features.6.weight", "cnn.cnn_model.features.6.bias", "cnn.cnn_model.embeddings.2.weight",
+                 "mla.embedded_mappings.1.fc.0.weight", "mla.fc.weight", "mla.fc.bias")
+
+
 def gen_train(ref_model):
     """train.py:119-142 semantics on the reference Ensemble: frozen CNN (default) and finetune."""
     g = {}
     dev = torch.device("cpu")
-    for tag, finetune, steps, B in (("frozen", False, 10, 8), ("finetune", True, 4, 4)):
+    # "refmain": the call ORDER of the reference's __main__ + train_model(finetune=True): the Adam is built from
+    # trainable_params() while the CNN is still frozen (train.py:369-370), set_requires_grad(clf, True) comes later
+    # (train.py:96-97) -- so gradients reach every parameter but the optimizer only ever steps the MLA head.
+    # "subset": a caller-made optimizer over an arbitrary parameter subset (one conv layer, one FC layer, one MLA layer)
+    # of a fully trainable model: optimizer.step() (train.py:138) updates exactly those.
+    for tag, finetune, steps, B in (("frozen", False, 10, 8), ("finetune", True, 4, 4), ("refmain", True, 4, 4), ("subset", True, 4, 4)):
         ens = ref_model.Ensemble("repeat", dict(CNN_CONF), [2, 1], dev)
         load_ref_state(ens, W.make_state_dict(7, W.ensemble_shapes((2, 1), False)))
-        if finetune:
+        if finetune and tag != "refmain":
             ref_model.set_requires_grad(ens, True)            # train.py:96-97
         params = [p for p in ens.parameters() if p.requires_grad]   # train.py:283-303
+        if tag == "subset":
+            params = [p for n, p in ens.named_parameters() if n in SUBSET_PARAMS]
         opt = torch.optim.Adam(params, lr=0.001)               # train.py:369
+        if tag == "refmain":
+            ref_model.set_requires_grad(ens, True)            # train.py:96-97, after the optimizer exists
         crit = torch.nn.CrossEntropyLoss()                     # train.py:372
         ens.train()
         losses, outs = [], []
@@ -287,7 +300,10 @@ def gen_train(ref_model):
         for k in ("mla.fc.weight", "mla.fc.bias", "mla.norm.running_mean", "mla.norm.running_var",
                   "mla.embedded_mappings.0.norm0.running_var", "mla.attention_modules.0.fcv.bias",
                   "mla.attention_modules.0.fcf.bias", "mla.embedded_mappings.1.fc.0.bias",
-                  "cnn.cnn_model.embeddings.4.bias", "cnn.cnn_model.features.0.bias"):
+                  "cnn.cnn_model.embeddings.4.bias", "cnn.cnn_model.features.0.bias", "cnn.cnn_model.features.6.bias",
+                  "mla.embedded_mappings.1.fc.0.weight"):
+            if tag in ("frozen", "finetune") and k in ("cnn.cnn_model.features.6.bias", "mla.embedded_mappings.1.fc.0.weight"):
+                continue                                       # (round-1 fixtures stay as they were)
             g["%s/final/%s" % (tag, k)] = fin[k].numpy().copy()
         # eval-mode logits after training (running statistics in use)
         ens.eval()

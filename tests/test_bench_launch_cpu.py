@@ -1,0 +1,61 @@
+"""`python bench.py --gpus N` from a plain shell must launch its own ranks (the driver's scaling run starts it that way):
+N child processes with the torch.distributed.run environment, spawned before the parent makes any GPU call, rank 0's
+JSON line relayed, a failing rank's exit code propagated and the surviving ranks stopped. `--dry-run` replaces the GPU
+work by a gloo rendezvous + one all-reduce, so the launch path itself runs here on CPU."""
+
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(*args, env=None):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, BENCH] + list(args), env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    return p.returncode, lines, p.stderr.decode()
+
+
+def test_self_launch_two_ranks_prints_one_line():
+    rc, lines, err = _run("--gpus", "2", "--dry-run", "--backend", "gloo")
+    assert rc == 0, err
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rank_sum"] == 1.0          # ranks 0 + 1 took part in the all-reduce
+
+
+def test_self_launch_train_mode_and_single():
+    rc, lines, err = _run("--gpus", "2", "--dry-run", "--mode", "train")
+    assert rc == 0 and json.loads(lines[0])["mode"] == "train", err
+    rc, lines, err = _run("--dry-run")
+    assert rc == 0 and json.loads(lines[0])["n_gpus"] == 1, err
+
+
+def test_failing_rank_propagates_and_stops_the_others():
+    rc, lines, err = _run("--gpus", "3", "--dry-run", "--dry-run-fail-rank", "1")
+    assert rc == 7 and "rank 1 exited with code 7" in err
+    assert lines == []
+
+
+def test_under_torchrun_environment_no_respawn():
+    """Started as ONE of the ranks (WORLD_SIZE set, as torch.distributed.run does): no children; a mismatch with --gpus is an error."""
+    rc, lines, err = _run("--gpus", "1", "--dry-run", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc == 0 and len(lines) == 1, err
+    rc, lines, err = _run("--gpus", "2", "--dry-run", env={"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and "WORLD_SIZE=4" in err
+
+
+def test_parent_makes_no_gpu_call_before_spawning():
+    """Static check of the order in main(): launch_ranks() is reached before any torch.cuda call."""
+    src = open(BENCH).read()
+    main = src[src.index("def main():"):src.index("def load_pmc_traffic")]
+    assert main.index("launch_ranks(") < main.index("torch.cuda.")
+    launch = src[src.index("def launch_ranks("):src.index("def dry_run(")]
+    assert "torch.cuda" not in launch and "os.exec" not in launch

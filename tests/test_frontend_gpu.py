@@ -186,3 +186,19 @@ def test_wavfile_to_examples_mono_and_stereo(vi, tmp_path, W):
     fl = W.waveform(42, n, 2, dtype=np.float64).T
     got = vi.waveform_to_examples(fl, 16000, return_tensor=False)
     assert np.abs(got - ofe.waveform_to_examples(fl.mean(axis=1))).max() <= 1e-4
+
+
+def test_waveform_to_examples_never_rescales_integer_input(vi, W):
+    """vggish_input.py:30-82 uses the values it is given (numpy promotes int16 to float64 unchanged); only
+    wavfile_to_examples divides by 32768 (vggish_input.py:97-98). An int16 array handed to the public drop-in therefore
+    yields the log-mel of the UNSCALED samples (about ln(32768) above the scaled one), for ndarray and tensor, mono and stereo."""
+    n = 15360 + 400
+    i16 = np.round(W.waveform(43, n, 2, dtype=np.float64).T * 20000).astype(np.int16)           # (n, 2)
+    for data, ref_in in ((i16[:, 0].copy(), i16[:, 0].astype(np.float64)), (i16, i16.astype(np.float64).mean(axis=1))):
+        ref = ofe.waveform_to_examples(ref_in)
+        for arg in (data, torch.from_numpy(data.copy())):
+            got = vi.waveform_to_examples(arg, 16000, return_tensor=False)
+            assert got.shape == ref.shape == (1, 96, 64)
+            assert np.abs(got - ref).max() <= 1e-4
+    scaled = ofe.waveform_to_examples(i16[:, 0] / 32768.0)
+    assert np.abs(ofe.waveform_to_examples(i16[:, 0].astype(np.float64)) - scaled).mean() > 5.0   # the two readings differ by ~ln(32768)

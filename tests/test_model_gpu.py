@@ -115,7 +115,7 @@ def test_conv_stack_layer_by_layer(ops, vg, W, mk, n_frames):
         got = ops.conv(layer, refq[layer - 2].cuda().to(torch.bfloat16), wp, convs[layer - 1].bias.detach())
         assert rel_err(got.float().cpu(), refq[layer - 1]) < 1e-2, "conv layer %d (bf16)" % layer
     outb = feats.forward_nhwc(x.cuda(), torch.bfloat16)
-    assert rel_err(outb.float().cpu(), ref[-1]) < 5e-2          # end-to-end bf16 vs f32 oracle (measured, not 1e-4)
+    assert rel_err(outb.float().cpu(), ref[-1]) < 1e-2          # end-to-end bf16 vs f32 oracle: measured 3-4e-3 (bound = 3x that; the 1e-4 modes are f32 and bf16x3)
 
 
 def test_vggish_embeddings_match_reference_golden(vg, golden, mk, W):
@@ -146,7 +146,7 @@ def test_vggish_embeddings_match_reference_golden(vg, golden, mk, W):
     # bf16 mode: measured deviation from the f32 reference, reported in DESIGN.md
     net.set_precision("bf16")
     embb = net(x)
-    assert rel_err(embb.cpu(), g["embedding"]) < 5e-2
+    assert rel_err(embb.cpu(), g["embedding"]) < 1e-2           # measured 3-4e-3
     # postprocessor (synthetic PCA parameters; the released ones need a network fetch)
     pp = vg.Postprocessor()
     pp.load_state_dict({"pca_eigen_vectors": torch.as_tensor(W.uniform(2, W.stream_id("pca_eigen_vectors"), 128 * 128).reshape(128, 128) * 0.5),
@@ -220,7 +220,7 @@ def test_ensemble_wave_to_logits_matches_reference_golden(model, golden, W, jb):
     out3 = ens.forward_waveforms(pcm)
     err = rel_err(out3.cpu(), ref)
     print("bf16 wave->logits rel err vs f32 reference (jb=%d): %.3g" % (jb, err))
-    assert err < 5e-2
+    assert err < 1e-2                                           # measured 3.2e-3 ... 4.4e-3; a 3x regression fails
 
 
 def test_hip_graph_replay_reproduces_eager_forward(model, W):
@@ -260,11 +260,11 @@ def test_full_size_forward_properties(model, W):
         assert torch.equal(ens.forward_waveforms(pcm[:102]), out[:102])         # the 1 020-clip batch of the small-batch leg
         perm = torch.randperm(1024, generator=torch.Generator().manual_seed(3)).cuda()
         assert torch.equal(ens.forward_waveforms(pcm[perm].contiguous()), out[perm])
-        # oracle on two bags: bf16 deviation as measured elsewhere (< 5e-2 asserted, ~4e-3 typical)
+        # oracle on two bags: bf16 deviation as measured elsewhere (< 1e-2 asserted, 3-4e-3 measured)
         waves = base[:2].cpu().numpy().astype(np.float64)
         ex = torch.from_numpy(ofe.batch_examples(waves).astype(np.float32)).reshape(2, 10, 1, 96, 64)
         ref = omodel.ensemble_forward({k: torch.as_tensor(v) for k, v in sd.items()}, ex, (2, 1), False)
-        assert rel_err(out[:2].cpu(), ref.numpy()) < 5e-2
+        assert rel_err(out[:2].cpu(), ref.numpy()) < 1e-2
         ens.set_precision("f32")
         out32 = ens.forward_waveforms(pcm[:40])
         assert rel_err(out32[:2].cpu(), ref.numpy()) < 1e-4
