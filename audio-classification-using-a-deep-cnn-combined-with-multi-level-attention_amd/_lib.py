@@ -89,6 +89,14 @@ def lib():
         L.mla_conv_wgrad_workspace_floats.restype = i64
         L.mla_conv_wgrad.argtypes = [vp, vp, i64, ci, ci, ci, ci, vp, i64, vp, vp]
         L.mla_conv1_bwd.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp]
+        L.mla_conv_repack_dgrad_bf16.argtypes = [vp, i64, i64, vp, vp]
+        L.mla_maxpool2x2_bf16.argtypes = [vp, vp, i64, ci, ci, ci, vp]
+        L.mla_relu_pool_bwd_bf16_workspace_bytes.restype = i64
+        L.mla_relu_pool_bwd_bf16.argtypes = [vp, ci, vp, ci, vp, i64, ci, ci, ci, ci, vp, vp, vp]
+        L.mla_conv_wgrad_bf16.argtypes = [vp, vp, i64, ci, ci, ci, ci, vp, i64, vp, vp]
+        L.mla_conv1_bwd_bf16.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp]
+        L.mla_transpose_bf16.argtypes = [vp, i64, vp, i64, i64, i64, vp]
+        L.mla_col_sum_bf16.argtypes = [vp, i64, i64, i64, vp, vp, vp]
         u64 = ctypes.c_uint64
         L.mla_dropout_mask.argtypes = [vp, i64, u64, u64, u64, cf, vp]
         L.mla_comm_unique_id.argtypes = [vp]

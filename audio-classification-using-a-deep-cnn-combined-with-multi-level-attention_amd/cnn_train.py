@@ -1,11 +1,16 @@
 """Training-mode forward (activations kept) and backward of the VGGish CNN as HIP kernel calls
 (vggish.py:21-31 forward; its autograd backward in the reference, train.py:137 after
-train.py:96-97 made the CNN trainable). f32 only (exact MFMA), NHWC.
+train.py:96-97 made the CNN trainable). NHWC. Two arithmetic modes, chosen by the CNN's ``precision``:
+
+* "f32": exact f32 MFMA everywhere (parity mode: gradients within 1e-4 of the reference's autograd);
+* "bf16": bf16 activations, gradients and weight copies with f32 accumulation; weight and bias gradients are
+  produced in f32 and applied to the f32 master parameters (mixed precision; bf16 has f32's exponent range, so no
+  loss scaling). The bf16 weight copies are re-derived from the masters after every Adam step.
 
 Forward keeps, per conv layer, its input and its pre-pool post-ReLU output; the pooled layers
 run as conv (pool = 0) + mla_maxpool2x2 so that the pool/ReLU backward can route gradients to
-the first maximum of each window. Backward per layer: mla_relu_pool_bwd -> dZ; mla_conv_wgrad
-(dW), column sums (db); mla_conv3x3 with flipped/transposed weights (dgrad). The three Linear
+the first maximum of each window. Backward per layer: mla_relu_pool_bwd -> dZ (+ db on the way); mla_conv_wgrad
+(dW); mla_conv3x3 with flipped/transposed weights (dgrad). The three Linear
 layers use the MFMA GEMM on transposed copies, as the MLA head does."""
 
 import torch
@@ -25,38 +30,64 @@ def _parts(cnn_model):
     return cnn_model[0], [], "0.", None
 
 
-def forward(cnn_model, x):
-    """x: (N, 1, 96, 64) or (N, 96, 64) float32 -> ((N, 128) embeddings or (N, 12288) bottlenecks, tape)."""
+def forward(cnn_model, x, precision="f32"):
+    """x: (N, 1, 96, 64) or (N, 96, 64) float32 -> ((N, 128) float32 embeddings or (N, 12288) bottlenecks, tape)."""
     feats, fcs, _, _ = _parts(cnn_model)
     convs = feats._convs
+    dtype = torch.bfloat16 if precision == "bf16" else torch.float32
     x = x.detach().reshape(-1, 96, 64).float().contiguous()
-    tape = {"x": x, "layers": {}}
-    cur = ops.conv1(x, convs[0].weight.detach().contiguous(), convs[0].bias.detach(), torch.float32)
+    tape = {"x": x, "layers": {}, "dtype": dtype}
+    cur = ops.conv1(x, convs[0].weight.detach().contiguous(), convs[0].bias.detach(), dtype)
+    packed = feats._cache.get([c.weight for c in convs[1:]], dtype,
+                              lambda: [ops.repack_conv_weight(c.weight.detach().contiguous(), dtype) for c in convs[1:]])
     for layer in range(2, 7):
         cin, cout, H, W_, pooled = GEOM[layer]
         c = convs[layer - 1]
-        wp = ops.repack_conv_weight(c.weight.detach().contiguous(), torch.float32)
-        a = ops.conv3x3(cur, wp, c.bias.detach(), cout, pool=False, act=True)
+        a = ops.conv3x3(cur, packed[layer - 2], c.bias.detach(), cout, pool=False, act=True)
         tape["layers"][layer] = (cur, a)
         cur = ops.maxpool2x2(a) if pooled else a
     h = cur.reshape(cur.shape[0], -1)
     tape["fc"] = []
-    for f in fcs:
-        out = ops.linear(h, f.weight.detach(), f.bias.detach(), relu=True)
-        tape["fc"].append((h, out))
-        h = out
+    if fcs:
+        if dtype == torch.float32:
+            ws = [f.weight.detach() for f in fcs]
+        else:
+            ws = cnn_model.embeddings._cache.get([f.weight for f in fcs], dtype, lambda: [ops.to_bf16(f.weight.detach().contiguous()) for f in fcs])
+        tape["fc_w"] = ws
+        for i, (f, w) in enumerate(zip(fcs, ws)):
+            last = i == len(fcs) - 1
+            out = ops.linear(h, w, f.bias.detach(), relu=True, out_dtype=torch.float32 if last else dtype)
+            tape["fc"].append((h, out))
+            h = out
+    elif dtype != torch.float32:
+        h = ops.to_f32(h)                       # just_bottlenecks: the head takes float32 features
     return h, tape
 
 
-def backward(cnn_model, tape, d_out, grads, prefix):
-    """d_out: gradient w.r.t. forward()'s result. Fills grads[prefix + <state_dict key>] for every CNN parameter that HAS
-    an entry in `grads` (weights in state_dict layout). Parameters without an entry get no gradient (they are frozen or
-    not held by the caller's optimizer), and the chain of input gradients stops at the lowest layer that has one."""
+def _linear_backward_bf16(x_in, w_bf16, dz, g_w, g_b, want_dx):
+    """bf16 form of mla_train._linear_backward: x_in (M, Kin), dz (M, N), w_bf16 (N, Kin), all bf16; g_w / g_b f32 (or None)."""
+    if g_w is not None:
+        ops.linear(ops.transpose_padded(dz), ops.transpose_padded(x_in), None, out=g_w, out_dtype=torch.float32)
+    if g_b is not None:
+        ops.col_sum(dz, g_b)
+    if not want_dx:
+        return None
+    return ops.linear(dz, ops.transpose_padded(w_bf16), None, out_dtype=torch.bfloat16)
+
+
+def backward(cnn_model, tape, d_out, grads, prefix, after_layer=None):
+    """d_out: gradient w.r.t. forward()'s result (float32). Fills grads[prefix + <state_dict key>] for every CNN parameter that
+    HAS an entry in `grads` (float32, weights in state_dict layout). Parameters without an entry get no gradient (they are
+    frozen or not held by the caller's optimizer), and the chain of input gradients stops at the lowest layer that has one.
+    after_layer(pos): called when the gradients of layer `pos` (0..5 conv, 6..8 Linear) are complete -- the hook the
+    data-parallel step uses to start reducing finished gradient buckets while the layers below are still running."""
     feats, fcs, kf, ke = _parts(cnn_model)
     convs = feats._convs
+    lp = tape["dtype"] == torch.bfloat16
     conv_idx = [0, 3, 6, 8, 11, 13]
     fc_idx = [0, 2, 4]
     g = lambda key: grads.get(key)
+    done = after_layer or (lambda pos: None)
     conv_keys = [prefix + kf + "%d." % i for i in conv_idx]
     fc_keys = [prefix + ke + "%d." % i for i in fc_idx[:len(fcs)]] if fcs else []
     order = conv_keys + fc_keys                                     # bottom -> top
@@ -65,14 +96,20 @@ def backward(cnn_model, tape, d_out, grads, prefix):
         return
     lowest = wanted.index(True)
     d = d_out.contiguous()
+    if lp and not fcs:
+        d = ops.to_bf16(d)
     for i in range(len(fcs) - 1, -1, -1):
         pos = 6 + i
         if pos < lowest:
             return
         h_in, h_out = tape["fc"][i]
-        dz = ops.relu_pool_bwd(h_out, d, pool=False)
+        dz = ops.relu_pool_bwd(h_out, d, pool=False, bf16=lp)
         key = fc_keys[i]
-        d = mla_train._linear_backward(h_in, fcs[i].weight.detach(), dz, g(key + "weight"), g(key + "bias"), pos > lowest)
+        if lp:
+            d = _linear_backward_bf16(h_in, tape["fc_w"][i], dz, g(key + "weight"), g(key + "bias"), pos > lowest)
+        else:
+            d = mla_train._linear_backward(h_in, fcs[i].weight.detach(), dz, g(key + "weight"), g(key + "bias"), pos > lowest)
+        done(pos)
     n = tape["x"].shape[0]
     for layer in range(6, 1, -1):
         pos = layer - 1
@@ -85,10 +122,12 @@ def backward(cnn_model, tape, d_out, grads, prefix):
         dz = ops.relu_pool_bwd(a, d.contiguous(), pool=pooled, db=g(key + "bias"))     # bias gradient summed on the way
         if g(key + "weight") is not None:
             ops.conv_wgrad(dz, a_in, g(key + "weight"))
+        done(pos)
         if pos > lowest:
-            wd = ops.repack_dgrad(convs[layer - 1].weight.detach().contiguous())
+            wd = ops.repack_dgrad(convs[layer - 1].weight.detach().contiguous(), tape["dtype"])
             d = ops.conv3x3(dz, wd, None, cin, pool=False, act=False)
     key = conv_keys[0]
     dw = g(key + "weight") if g(key + "weight") is not None else torch.empty((64, 1, 3, 3), dtype=torch.float32, device=d.device)
     db = g(key + "bias") if g(key + "bias") is not None else torch.empty(64, dtype=torch.float32, device=d.device)
     ops.conv1_bwd(tape["x"], convs[0].weight.detach().contiguous(), convs[0].bias.detach(), d.contiguous(), dw, db)
+    done(0)

@@ -1,0 +1,503 @@
+// cnn_train_bf16.hip -- the finetune backward of the VGGish feature stack in bf16 (train.py:96-97 set_requires_grad(clf, True),
+// then loss.backward() at train.py:137 reaches the CNN): bf16 activations and gradients, f32 accumulation, f32 weight
+// gradients into the flat gradient buffer, f32 master weights (the bf16 weight copies are re-derived after every Adam step).
+// The f32 forms (exact-MFMA parity mode) live in cnn_train.hip; this file is what the step runs in at speed.
+//
+//   maxpool2x2_bf16       nn.MaxPool2d(2, 2) on a kept pre-pool activation, 8 channels (16 B) per lane
+//   relu_pool_bwd_bf16    dZ from the gradient of relu(.) / maxpool(relu(.)): first-maximum routing (torch's tie rule) and
+//                         ReLU mask; the layer's bias gradient (column sums of dZ) is accumulated on the way
+//   wgrad_bf16            dW[co][tap][ci] = sum_pixels dZ[p][co] * A[p + tap][ci] as an implicit GEMM with K = pixels on
+//                         v_mfma_f32_16x16x32_bf16. NHWC keeps a pixel's channels contiguous while the MFMA wants 8
+//                         consecutive k (pixels) of ONE channel per lane: the staged [pixel][channel] tiles are read with
+//                         ds_read_b64_tr_b16 (gfx950's transposing LDS read: a 16-lane group fetches 4 pixel rows x 16
+//                         channels and each lane receives one channel's 4 pixels), so no transposed copy of dZ or of the
+//                         activations ever exists. The order of the 32 pixels inside a k-step is chosen so that each
+//                         32-lane half reads 8 CONSECUTIVE pixel rows: with a 160-byte row pitch these are 8 distinct
+//                         32-byte bank slots -- conflict-free for every tap shift.
+//   conv1_bwd (bf16 dY)   Cin = 1 special case of cnn_train.hip with the incoming gradient in bf16
+//   transpose_bf16, col_sum_bf16   helpers of the Linear backward (K-contiguous operands for the MFMA GEMM; bias gradients)
+//
+// Roofline: wgrad is MFMA-bound (2 * pixels * 9 Cin Cout flop per image, the same as the forward layer); the elementwise
+// kernels are HBM-bound (they read and write each activation-sized tensor once).
+#include "common.h"
+#include "mma_core.h"
+
+namespace {
+
+using namespace mma;
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// eight consecutive channels as floats, from bf16 (one 16-byte load) or f32 (two)
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* v);
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float* v) {
+    const u32x4 u = *reinterpret_cast<const u32x4*>(p);
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) {
+        v[2 * k] = __builtin_bit_cast(float, u[k] << 16);
+        v[2 * k + 1] = __builtin_bit_cast(float, u[k] & 0xffff0000u);
+    }
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, float* v) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(p)[0], b = reinterpret_cast<const f32x4*>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float* v) {
+    *reinterpret_cast<u32x4*>(p) = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+}
+
+__global__ __launch_bounds__(256) void maxpool_bf16_kernel(const bf16_t* __restrict__ a, bf16_t* __restrict__ out, int64_t n_out,
+                                                           int H, int W, int C) {
+    const int c8 = C / 8, WO = W / 2, HO = H / 2;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n_out; i += int64_t(gridDim.x) * 256) {
+        const int c = int(i % c8);
+        int64_t r = i / c8;
+        const int xo = int(r % WO); r /= WO;
+        const int yo = int(r % HO);
+        const int64_t n = r / HO;
+        const bf16_t* p = a + ((n * H + 2 * yo) * W + 2 * xo) * C + c * 8;
+        float v00[8], v01[8], v10[8], v11[8], m[8];
+        load8(p, v00); load8(p + C, v01); load8(p + int64_t(W) * C, v10); load8(p + int64_t(W) * C + C, v11);
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) m[k] = fmaxf(fmaxf(v00[k], v01[k]), fmaxf(v10[k], v11[k]));
+        store8(out + i * 8, m);                              // max of bf16 values is a bf16 value: the repack is exact
+    }
+}
+
+// One lane per (n, yo, xo, 8 channels) [pool] or per 8 consecutive elements [no pool]; dZ in bf16. The grid-stride step is
+// a multiple of C / 8, so a lane's 8 channels never change: their dZ sums go to slots[(block * 256 + t) * 8 + k] in double
+// precision and bias_slots_finish8 adds the slots of a channel in fixed order (deterministic).
+template <typename TA, typename TD>
+__global__ __launch_bounds__(256) void relu_pool_bwd_bf16_kernel(const TA* __restrict__ a, const TD* __restrict__ d_out,
+                                                                 bf16_t* __restrict__ dz, int64_t total8, int H, int W, int C, int pool,
+                                                                 double* __restrict__ slots) {
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int c8 = C / 8;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < total8; i += int64_t(gridDim.x) * 256) {
+        float g[8], d[8];
+        load8(d_out + i * 8, d);
+        if (!pool) {
+            float av[8];
+            load8(a + i * 8, av);
+            _Pragma("unroll") for (int k = 0; k < 8; ++k) g[k] = av[k] > 0.f ? d[k] : 0.f;
+            store8(dz + i * 8, g);
+        } else {
+            const int WO = W / 2, HO = H / 2;
+            const int c = int(i % c8);
+            int64_t r = i / c8;
+            const int xo = int(r % WO); r /= WO;
+            const int yo = int(r % HO);
+            const int64_t n = r / HO;
+            const int64_t base = ((n * H + 2 * yo) * W + 2 * xo) * C + c * 8;
+            const int64_t off[4] = {0, C, int64_t(W) * C, int64_t(W) * C + C};
+            float v[4][8];
+            _Pragma("unroll") for (int w = 0; w < 4; ++w) load8(a + base + off[w], v[w]);
+            int arg[8];
+            _Pragma("unroll") for (int k = 0; k < 8; ++k) {
+                float best = v[0][k];
+                arg[k] = 0;
+                _Pragma("unroll") for (int w = 1; w < 4; ++w)
+                    if (v[w][k] > best) { best = v[w][k]; arg[k] = w; }
+                g[k] = best > 0.f ? d[k] : 0.f;
+            }
+            _Pragma("unroll") for (int w = 0; w < 4; ++w) {
+                float o[8];
+                _Pragma("unroll") for (int k = 0; k < 8; ++k) o[k] = arg[k] == w ? g[k] : 0.f;
+                store8(dz + base + off[w], o);
+            }
+        }
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) acc[k] += double(g[k]);
+    }
+    if (slots) {
+        double* s = slots + (int64_t(blockIdx.x) * 256 + threadIdx.x) * 8;
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) s[k] = acc[k];
+    }
+}
+
+// db[c]: lane t of block b holds channels 8 ((b * 256 + t) % (C / 8)) + k
+__global__ __launch_bounds__(256) void bias_slots_finish8_kernel(const double* __restrict__ slots, int64_t n_lanes, int C,
+                                                                 float* __restrict__ db) {
+    __shared__ double part[256];
+    const int c = blockIdx.x, c8 = C / 8, grp = c / 8, k = c % 8;
+    double s = 0.0;
+    for (int64_t l = int64_t(grp) + int64_t(threadIdx.x) * c8; l < n_lanes; l += int64_t(256) * c8) s += slots[l * 8 + k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (int(threadIdx.x) < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) db[c] = float(part[0]);
+}
+
+// ------------------------------------------------------------------------------------ wgrad ---
+template <int CIN, int COUT, int H, int W>
+struct WBCfg {
+    static constexpr int TH = W == 32 ? 4 : (W == 16 ? 8 : 12);        // image rows per staged band
+    static constexpr int KSTEPS = TH * W / 32;                         // 32 pixels per MFMA k-step
+    static constexpr int BANDS = H / TH;
+    static constexpr int PW = W + 2, PH = TH + 2;
+    static constexpr int PITCH = 160;                                  // bytes per staged pixel: 64 bf16 + 32 B (bank spread)
+    static constexpr int Z_BYTES = TH * W * PITCH, A_BYTES = PH * PW * PITCH;
+    static constexpr int LDS_BYTES = Z_BYTES + A_BYTES;
+    static constexpr int TILES_CO = COUT / 64, TILES_CI = CIN / 64;
+    static_assert(H % TH == 0 && (TH * W) % 32 == 0 && COUT % 64 == 0 && CIN % 64 == 0 && 2 * LDS_BYTES <= 160 * 1024, "wgrad tiling");
+};
+
+__device__ __forceinline__ s16x4 tr_read(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+__device__ __forceinline__ bf16x8 frag_of(s16x4 lo, s16x4 hi) {
+    return __builtin_bit_cast(bf16x8, s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w});
+}
+
+template <typename C, int CIN, int COUT, int H, int W>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ ain,
+                                                            float* __restrict__ partial, int n_img) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sZ = smem;
+    char* sA = smem + C::Z_BYTES;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
+    const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;      // transposing read: lane 4 q4 + p4 of its group
+    const int r = lane & 15, q = lane >> 4;                                  // supplies pixel row q4, channels 4 p4 .. 4 p4 + 3
+    const int co0 = (blockIdx.x / C::TILES_CI) * 64, ci0 = (blockIdx.x % C::TILES_CI) * 64;
+    const int split = blockIdx.y, splits = gridDim.y;
+
+    // pixel (y, x) of k-step s, half h (elements 4h .. 4h+3 of the fragment), lane group g, row q4 of the 4-pixel block:
+    //   W = 32: y = s,               x = 16 h + 4 g + q4      W = 16: y = 2 s + h, x = 4 g + q4
+    //   W = 8 : y = 4 s + 2 h + (g >> 1), x = 4 (g & 1) + q4
+    // per lane: ly / lx = the (g, q4)-dependent part; the (s, h) part is a compile-time constant
+    const int ly = W == 8 ? (g >> 1) : 0;
+    const int lx = (W == 8 ? 4 * (g & 1) : 4 * g) + q4;
+    const int zlane = (ly * W + lx) * C::PITCH + 8 * p4;                    // + channel tile * 32 B + (s, h) pixel offset
+    const int alane = (ly * C::PW + lx) * C::PITCH + 8 * p4;
+    auto sh_y = [](int s, int h) { return W == 32 ? s : (W == 16 ? 2 * s + h : 4 * s + 2 * h); };
+    auto sh_x = [](int h) { return W == 32 ? 16 * h : 0; };
+
+    f32x4 acc[2][2][9];
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)
+            _Pragma("unroll") for (int k = 0; k < 9; ++k) acc[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int img = split; img < n_img; img += splits) {
+        for (int band = 0; band < C::BANDS; ++band) {
+            const int y0 = band * C::TH;
+            __syncthreads();
+            // stage dZ rows y0 .. y0+TH-1 (64 output channels) and the input patch with halo (64 input channels)
+            for (int p = t; p < C::TH * W * 8; p += 256) {
+                const int ch = p & 7, pix = p >> 3;
+                const int x = pix % W, y = pix / W;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(dz + ((size_t(img) * H + y0 + y) * W + x) * COUT + co0 + ch * 8);
+                *reinterpret_cast<u32x4*>(sZ + pix * C::PITCH + ch * 16) = v;
+            }
+            for (int p = t; p < C::PH * C::PW * 8; p += 256) {
+                const int ch = p & 7, pix = p >> 3;
+                const int xh = pix % C::PW, yh = pix / C::PW;
+                const int gy = y0 + yh - 1, gx = xh - 1;
+                u32x4 v = zero16();
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                    v = *reinterpret_cast<const u32x4*>(ain + ((size_t(img) * H + gy) * W + gx) * CIN + ci0 + ch * 8);
+                *reinterpret_cast<u32x4*>(sA + pix * C::PITCH + ch * 16) = v;
+            }
+            __syncthreads();
+            _Pragma("unroll") for (int s = 0; s < C::KSTEPS; ++s) {
+                bf16x8 za[2];
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) {
+                    s16x4 part[2];
+                    _Pragma("unroll") for (int h = 0; h < 2; ++h)
+                        part[h] = tr_read(sZ + zlane + (sh_y(s, h) * W + sh_x(h)) * C::PITCH + (wr * 2 + i) * 32);
+                    za[i] = frag_of(part[0], part[1]);
+                }
+                _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {
+                    bf16x8 ab[3][2];
+                    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)
+                        _Pragma("unroll") for (int j = 0; j < 2; ++j) {
+                            s16x4 part[2];
+                            _Pragma("unroll") for (int h = 0; h < 2; ++h)
+                                part[h] = tr_read(sA + alane + ((sh_y(s, h) + ky) * C::PW + sh_x(h) + kx) * C::PITCH + (wc * 2 + j) * 32);
+                            ab[kx][j] = frag_of(part[0], part[1]);
+                        }
+                    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)
+                        _Pragma("unroll") for (int i = 0; i < 2; ++i)
+                            _Pragma("unroll") for (int j = 0; j < 2; ++j)
+                                acc[i][j][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[i], ab[kx][j], acc[i][j][ky * 3 + kx], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // partial[split][co][tap][ci]; C/D layout: col = lane & 15 (ci), row = 4 (lane >> 4) + reg (co)
+    float* out = partial + size_t(split) * COUT * 9 * CIN;
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)
+            _Pragma("unroll") for (int k = 0; k < 9; ++k) {
+                const float v[4] = {acc[i][j][k].x, acc[i][j][k].y, acc[i][j][k].z, acc[i][j][k].w};
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {
+                    const int co = co0 + (wr * 2 + i) * 16 + 4 * q + e, ci = ci0 + (wc * 2 + j) * 16 + r;
+                    out[(size_t(co) * 9 + k) * CIN + ci] = v[e];
+                }
+            }
+}
+
+// dW[co][ci][tap] (state_dict layout) = sum over splits of partial[split][co][tap][ci]
+__global__ __launch_bounds__(256) void wgrad_reduce_bf16_kernel(const float* __restrict__ partial, int splits, int cout, int cin,
+                                                                float* __restrict__ dw) {
+    const int64_t total = int64_t(cout) * cin * 9;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < total; i += int64_t(gridDim.x) * 256) {
+        const int tap = int(i % 9);
+        const int ci = int((i / 9) % cin);
+        const int co = int(i / (int64_t(9) * cin));
+        const size_t src = (size_t(co) * 9 + tap) * cin + ci;
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += partial[size_t(k) * total + src];
+        dw[i] = s;
+    }
+}
+
+template <int CIN, int COUT, int H, int W>
+int launch_wgrad_bf16(const bf16_t* dz, const bf16_t* ain, int64_t n, float* partial, int64_t partial_floats, float* dw, hipStream_t s) {
+    using C = WBCfg<CIN, COUT, H, W>;
+    const int tiles = C::TILES_CO * C::TILES_CI;
+    int splits = (768 + tiles - 1) / tiles;
+    if (splits > n) splits = int(n);
+    const int64_t need = int64_t(splits) * COUT * 9 * CIN;
+    MLA_REQUIRE(partial_floats >= need, MLA_E_ARG, "wgrad workspace too small: %lld < %lld floats", (long long)partial_floats, (long long)need);
+    auto kern = wgrad_bf16_kernel<C, CIN, COUT, H, W>;
+    MLA_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), C::LDS_BYTES, s, dz, ain, partial, int(n));
+    MLA_LAUNCH_OK("wgrad_bf16_kernel");
+    hipLaunchKernelGGL(wgrad_reduce_bf16_kernel, dim3(1024), dim3(256), 0, s, partial, splits, COUT, CIN, dw);
+    MLA_LAUNCH_OK("wgrad_reduce_bf16_kernel");
+    return MLA_OK;
+}
+
+// ----------------------------------------------------------------------------- conv1 backward ---
+// as conv1_bwd_kernel of cnn_train.hip, the incoming gradient in bf16
+__global__ __launch_bounds__(256) void conv1_bwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, const bf16_t* __restrict__ d_pooled,
+                                                             int64_t n_pix, float* __restrict__ partial) {
+    __shared__ float red[4][80];
+    const int cg = blockIdx.y;
+    float gw[8][9], gb[8];
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) {
+        gb[c] = 0.f;
+        _Pragma("unroll") for (int k = 0; k < 9; ++k) gw[c][k] = 0.f;
+    }
+    for (int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x; idx < n_pix; idx += int64_t(gridDim.x) * 256) {
+        const int px = int(idx & 31), py = int((idx >> 5) % 48);
+        const int64_t n = idx / (48 * 32);
+        float patch[4][4];
+        _Pragma("unroll") for (int a = 0; a < 4; ++a)
+            _Pragma("unroll") for (int b = 0; b < 4; ++b) {
+                const int iy = 2 * py - 1 + a, ix = 2 * px - 1 + b;
+                patch[a][b] = (iy >= 0 && iy < 96 && ix >= 0 && ix < 64) ? x[(n * 96 + iy) * 64 + ix] : 0.f;
+            }
+        float dv[8];
+        load8(d_pooled + idx * 64 + cg * 8, dv);
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) {
+            const int ch = cg * 8 + c;
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+            _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)
+                _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {
+                    const float wv = w[ch * 9 + ky * 3 + kx];
+                    o[0] = fmaf(patch[ky][kx], wv, o[0]);
+                    o[1] = fmaf(patch[ky][kx + 1], wv, o[1]);
+                    o[2] = fmaf(patch[ky + 1][kx], wv, o[2]);
+                    o[3] = fmaf(patch[ky + 1][kx + 1], wv, o[3]);
+                }
+            float best = o[0];
+            int arg = 0;
+            _Pragma("unroll") for (int k = 1; k < 4; ++k)
+                if (o[k] > best) { best = o[k]; arg = k; }
+            const float gg = (best + bias[ch] > 0.f) ? dv[c] : 0.f;
+            gb[c] += gg;
+            const int dy = arg >> 1, dx = arg & 1;
+            _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)
+                _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {
+                    const float v = dy ? (dx ? patch[ky + 1][kx + 1] : patch[ky + 1][kx]) : (dx ? patch[ky][kx + 1] : patch[ky][kx]);
+                    gw[c][ky * 3 + kx] = fmaf(gg, v, gw[c][ky * 3 + kx]);
+                }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) {
+        _Pragma("unroll") for (int k = 0; k < 10; ++k) {
+            float v = k < 9 ? gw[c][k] : gb[c];
+            _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0) red[wave][c * 10 + k] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 80)
+        partial[(size_t(blockIdx.x) * 8 + cg) * 80 + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void conv1_bwd_finish_bf16_kernel(const float* __restrict__ partial, int blocks, float* __restrict__ dw, float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;           // 0 .. 639: (cg, c, k)
+    if (i >= 640) return;
+    const int cg = i / 80, rem = i % 80, c = rem / 10, k = rem % 10;
+    double s = 0.0;
+    for (int b = 0; b < blocks; ++b) s += partial[(size_t(b) * 8 + cg) * 80 + rem];
+    if (k < 9) dw[(cg * 8 + c) * 9 + k] = float(s);
+    else db[cg * 8 + c] = float(s);
+}
+
+// ------------------------------------------------------------------- Linear-backward helpers ---
+// out[c][r] = in[r][c] for 2-byte elements; 64 x 64 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __restrict__ in, int64_t ld_in, uint16_t* __restrict__ out,
+                                                             int64_t ld_out, int64_t rows, int64_t cols) {
+    __shared__ uint16_t tile[64][66];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 x 4
+    const int64_t c0 = int64_t(blockIdx.x) * 64, r0 = int64_t(blockIdx.y) * 64;
+    _Pragma("unroll") for (int j = 0; j < 64; j += 4) {
+        const int64_t r = r0 + ty + j, c = c0 + tx;
+        tile[ty + j][tx] = (r < rows && c < cols) ? in[r * ld_in + c] : uint16_t(0);
+    }
+    __syncthreads();
+    _Pragma("unroll") for (int j = 0; j < 64; j += 4) {
+        const int64_t c = c0 + ty + j, r = r0 + tx;
+        if (c < cols && r < ld_out) out[c * ld_out + r] = r < rows ? tile[tx][ty + j] : uint16_t(0);     // zero the row padding too
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_partial_bf16_kernel(const bf16_t* __restrict__ x, int64_t ldx, int64_t rows, int cols,
+                                                                  double* __restrict__ partial) {
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = int64_t(blockIdx.y) * per, r1 = r0 + per < rows ? r0 + per : rows;
+    double s = 0.0;
+    if (c < cols)
+        for (int64_t r = r0 + g; r < r1; r += 4) s += double(bf2f(x[r * ldx + c].bits));
+    part[g][lane] = s;
+    __syncthreads();
+    if (g == 0 && c < cols) partial[int64_t(blockIdx.y) * cols + c] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+}
+
+__global__ void colsum_finish_bf16_kernel(const double* __restrict__ partial, int chunks, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    double s = 0.0;
+    for (int k = 0; k < chunks; ++k) s += partial[int64_t(k) * cols + c];
+    out[c] = float(s);
+}
+
+// (Cout, Cin, 3, 3) f32 -> (Cin, 9, Cout) bf16 with the taps flipped: weights of the dgrad convolution
+__global__ void repack_dgrad_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int cout, int cin) {
+    const int64_t total = int64_t(cout) * 9 * cin;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+        const int co = int(i % cout);
+        const int tap = int((i / cout) % 9);
+        const int ci = int(i / (int64_t(cout) * 9));
+        out[i].bits = f2bf(w[(int64_t(co) * cin + ci) * 9 + (8 - tap)]);
+    }
+}
+
+constexpr int kBiasGrid8 = 1024;
+
+}  // namespace
+
+extern "C" int mla_maxpool2x2_bf16(const void* a, void* out, int64_t n, int H, int W, int C, mla_stream_t stream) {
+    MLA_REQUIRE(a && out && n >= 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0, MLA_E_ARG, "bad maxpool arguments");
+    MLA_REQUIRE(mla::aligned(a, 16) && mla::aligned(out, 16), MLA_E_ARG, "maxpool buffers must be 16-byte aligned");
+    const int64_t total = n * (H / 2) * (W / 2) * (C / 8);
+    if (total == 0) return MLA_OK;
+    const unsigned grid = unsigned((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(maxpool_bf16_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(a),
+                       static_cast<bf16_t*>(out), total, H, W, C);
+    MLA_LAUNCH_OK("maxpool_bf16");
+    return MLA_OK;
+}
+
+extern "C" int64_t mla_relu_pool_bwd_bf16_workspace_bytes(void) { return int64_t(kBiasGrid8) * 256 * 8 * 8; }
+
+extern "C" int mla_relu_pool_bwd_bf16(const void* a, int a_dtype, const void* d_out, int d_dtype, void* dz, int64_t n, int H, int W,
+                                      int C, int pool, void* workspace, float* db, mla_stream_t stream) {
+    MLA_REQUIRE(a && d_out && dz && n > 0, MLA_E_ARG, "bad relu_pool_bwd arguments");
+    MLA_REQUIRE((a_dtype == MLA_BF16 && d_dtype == MLA_BF16) || (a_dtype == MLA_F32 && d_dtype == MLA_F32), MLA_E_DTYPE,
+                "relu_pool_bwd_bf16: a / d_out dtypes %d / %d (both bf16, or both f32)", a_dtype, d_dtype);
+    MLA_REQUIRE(C > 0 && C % 8 == 0 && (kBiasGrid8 * 256) % (C / 8) == 0, MLA_E_SHAPE, "channel count %d", C);
+    MLA_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0), MLA_E_SHAPE, "pooling needs even H, W");
+    MLA_REQUIRE(!db || workspace, MLA_E_ARG, "the bias gradient needs the workspace");
+    MLA_REQUIRE(mla::aligned(a, 16) && mla::aligned(d_out, 16) && mla::aligned(dz, 16), MLA_E_ARG, "buffers must be 16-byte aligned");
+    const int64_t total8 = (pool ? n * (H / 2) * (W / 2) * C : n * H * W * C) / 8;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* slots = db ? static_cast<double*>(workspace) : nullptr;
+    if (a_dtype == MLA_BF16)
+        hipLaunchKernelGGL((relu_pool_bwd_bf16_kernel<bf16_t, bf16_t>), dim3(kBiasGrid8), dim3(256), 0, s, static_cast<const bf16_t*>(a),
+                           static_cast<const bf16_t*>(d_out), static_cast<bf16_t*>(dz), total8, H, W, C, pool, slots);
+    else
+        hipLaunchKernelGGL((relu_pool_bwd_bf16_kernel<float, float>), dim3(kBiasGrid8), dim3(256), 0, s, static_cast<const float*>(a),
+                           static_cast<const float*>(d_out), static_cast<bf16_t*>(dz), total8, H, W, C, pool, slots);
+    MLA_LAUNCH_OK("relu_pool_bwd_bf16");
+    if (db) {
+        hipLaunchKernelGGL(bias_slots_finish8_kernel, dim3(unsigned(C)), dim3(256), 0, s, slots, int64_t(kBiasGrid8) * 256, C, db);
+        MLA_LAUNCH_OK("bias_slots_finish8");
+    }
+    return MLA_OK;
+}
+
+extern "C" int mla_conv_wgrad_bf16(const void* dz, const void* a_in, int64_t n, int H, int W, int cin, int cout, float* workspace,
+                                   int64_t workspace_floats, float* dw_oihw, mla_stream_t stream) {
+    MLA_REQUIRE(dz && a_in && workspace && dw_oihw && n > 0, MLA_E_ARG, "bad wgrad arguments");
+    MLA_REQUIRE(mla::aligned(dz, 16) && mla::aligned(a_in, 16), MLA_E_ARG, "wgrad operands must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bf16_t* z = static_cast<const bf16_t*>(dz);
+    const bf16_t* a = static_cast<const bf16_t*>(a_in);
+#define MLA_WGRAD_CASE(CI, CO, HH, WW) \
+    if (cin == CI && cout == CO && H == HH && W == WW) return launch_wgrad_bf16<CI, CO, HH, WW>(z, a, n, workspace, workspace_floats, dw_oihw, s);
+    MLA_WGRAD_CASE(64, 128, 48, 32)
+    MLA_WGRAD_CASE(128, 256, 24, 16)
+    MLA_WGRAD_CASE(256, 256, 24, 16)
+    MLA_WGRAD_CASE(256, 512, 12, 8)
+    MLA_WGRAD_CASE(512, 512, 12, 8)
+#undef MLA_WGRAD_CASE
+    return mla::fail(MLA_E_SHAPE, "wgrad %dx%d %d->%d is not compiled", H, W, cin, cout);
+}
+
+extern "C" int mla_conv1_bwd_bf16(const float* x, const float* w, const float* bias, const void* d_pooled, int64_t n, float* workspace,
+                                  float* dw, float* db, mla_stream_t stream) {
+    MLA_REQUIRE(x && w && bias && d_pooled && workspace && dw && db && n > 0, MLA_E_ARG, "bad conv1_bwd arguments");
+    const int64_t n_pix = n * 48 * 32;
+    const int blocks = int((n_pix + 255) / 256 < 1024 ? (n_pix + 255) / 256 : 1024);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(conv1_bwd_bf16_kernel, dim3(blocks, 8), dim3(256), 0, s, x, w, bias, static_cast<const bf16_t*>(d_pooled), n_pix, workspace);
+    MLA_LAUNCH_OK("conv1_bwd_bf16");
+    hipLaunchKernelGGL(conv1_bwd_finish_bf16_kernel, dim3(3), dim3(256), 0, s, workspace, blocks, dw, db);
+    MLA_LAUNCH_OK("conv1_bwd_finish_bf16");
+    return MLA_OK;
+}
+
+extern "C" int mla_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int64_t cols,
+                                  mla_stream_t stream) {
+    MLA_REQUIRE(in && out && rows > 0 && cols > 0 && ld_in >= cols && ld_out >= rows, MLA_E_ARG, "bad transpose arguments");
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(unsigned((cols + 63) / 64), unsigned((ld_out + 63) / 64)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const uint16_t*>(in), ld_in, static_cast<uint16_t*>(out), ld_out, rows, cols);
+    MLA_LAUNCH_OK("transpose_bf16");
+    return MLA_OK;
+}
+
+// workspace: 64 * cols doubles
+extern "C" int mla_col_sum_bf16(const void* x, int64_t ldx, int64_t rows, int64_t cols, void* workspace, float* out,
+                                mla_stream_t stream) {
+    MLA_REQUIRE(x && workspace && out && rows > 0 && cols > 0 && ldx >= cols, MLA_E_ARG, "bad col_sum arguments");
+    const int chunks = int(rows / 256 < 1 ? 1 : (rows / 256 > 64 ? 64 : rows / 256));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(colsum_partial_bf16_kernel, dim3(unsigned((cols + 63) / 64), unsigned(chunks)), dim3(256), 0, s,
+                       static_cast<const bf16_t*>(x), ldx, rows, int(cols), static_cast<double*>(workspace));
+    MLA_LAUNCH_OK("colsum partial bf16");
+    hipLaunchKernelGGL(colsum_finish_bf16_kernel, dim3(unsigned((cols + 255) / 256)), dim3(256), 0, s,
+                       static_cast<const double*>(workspace), chunks, int(cols), out);
+    MLA_LAUNCH_OK("colsum finish bf16");
+    return MLA_OK;
+}
+
+extern "C" int mla_conv_repack_dgrad_bf16(const float* w_oihw, int64_t cout, int64_t cin, void* out, mla_stream_t stream) {
+    MLA_REQUIRE(w_oihw && out && cout > 0 && cin > 0, MLA_E_ARG, "bad repack arguments");
+    const int64_t total = cout * 9 * cin;
+    const unsigned grid = unsigned((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(repack_dgrad_bf16_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), w_oihw,
+                       static_cast<bf16_t*>(out), int(cout), int(cin));
+    MLA_LAUNCH_OK("repack_dgrad_bf16_kernel");
+    return MLA_OK;
+}

@@ -578,13 +578,14 @@ __global__ void repack_dgrad_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
-// every compiled (H, W, Cin, Cout, pool, act) combination in f32: VGGish forward without the fused
-// pool (training keeps the pre-pool activations) and the five dgrad shapes
-int conv_generic_f32(const void* in, const void* w, const float* bias, void* out, int64_t n, int H, int W, int cin, int cout,
-                     bool pool, bool act, hipStream_t s) {
+// every compiled (H, W, Cin, Cout, pool, act) combination of the generic entry: VGGish forward with and without the
+// fused pool (training keeps the pre-pool activations) and the five dgrad shapes; f32 (exact) and bf16
+template <typename T>
+int conv_generic(const void* in, const void* w, const float* bias, void* out, int64_t n, int H, int W, int cin, int cout,
+                 bool pool, bool act, hipStream_t s) {
 #define MLA_CONV_CASE(CI, CO, HH, WW, PO, NS_, AC)                                                             \
     if (cin == CI && cout == CO && H == HH && W == WW && pool == PO && act == AC)                              \
-        return launch_conv<Cfg<float, CI, CO, HH, WW, PO, NS_, AC>>(in, w, bias, out, n, s);
+        return launch_conv<Cfg<T, CI, CO, HH, WW, PO, NS_, AC>>(in, w, bias, out, n, s);
     MLA_CONV_CASE(64, 128, 48, 32, true, 2, true)
     MLA_CONV_CASE(128, 256, 24, 16, false, 4, true)
     MLA_CONV_CASE(256, 256, 24, 16, true, 4, true)
@@ -610,8 +611,10 @@ extern "C" int mla_conv3x3(const void* in, const void* w_packed, const float* bi
     if (n == 0) return MLA_OK;
     MLA_REQUIRE(in && w_packed && out && (bias || !act), MLA_E_ARG, "null conv buffers");
     MLA_REQUIRE(mla::aligned(in, 16) && mla::aligned(w_packed, 16), MLA_E_ARG, "conv buffers must be 16-byte aligned");
-    MLA_REQUIRE(dtype == MLA_F32, MLA_E_DTYPE, "the generic conv entry (training / dgrad) is compiled for f32 only");
-    return conv_generic_f32(in, w_packed, bias, out, n, H, W, cin, cout, pool != 0, act != 0, static_cast<hipStream_t>(stream));
+    MLA_REQUIRE(dtype == MLA_F32 || dtype == MLA_BF16, MLA_E_DTYPE, "the generic conv entry (training / dgrad) is compiled for f32 and bf16");
+    if (dtype == MLA_BF16)
+        return conv_generic<bf16_t>(in, w_packed, bias, out, n, H, W, cin, cout, pool != 0, act != 0, static_cast<hipStream_t>(stream));
+    return conv_generic<float>(in, w_packed, bias, out, n, H, W, cin, cout, pool != 0, act != 0, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mla_conv_repack_dgrad(const float* w_oihw, int64_t cout, int64_t cin, float* out, mla_stream_t stream) {

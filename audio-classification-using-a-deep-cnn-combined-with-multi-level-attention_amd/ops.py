@@ -371,9 +371,15 @@ def linear_small_bwd(a, w, dz, dw, db):
 
 
 def transpose_padded(x):
-    """(R, C) f32 -> (C, ceil4(R)) with zero padding, K-contiguous for the MFMA GEMM."""
-    _chk(x, torch.float32)
+    """(R, C) f32 | bf16 -> (C, R~) with zero padding (R~ = R rounded up to a 16-byte row), K-contiguous for the MFMA GEMM."""
+    _chk(x)
     R, C = x.shape
+    if x.dtype == torch.bfloat16:
+        ld = (R + 7) // 8 * 8
+        out = torch.empty((C, ld), dtype=torch.bfloat16, device=x.device)
+        _lib.check(_lib.lib().mla_transpose_bf16(_p(x), x.stride(0), _p(out), ld, R, C, _lib.stream_ptr()))
+        return out
+    _chk(x, torch.float32)
     ld = (R + 3) // 4 * 4
     out = torch.zeros((C, ld), dtype=torch.float32, device=x.device) if ld != R else torch.empty((C, ld), dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().mla_transpose_f32(_p(x), x.stride(0), _p(out), ld, R, C, _lib.stream_ptr()))
@@ -381,13 +387,14 @@ def transpose_padded(x):
 
 
 def col_sum(x, out):
-    _chk(x, torch.float32)
+    _chk(x)
     rows, cols = x.shape
     key = "colsum/" + str(x.device)
     if key not in _ws or _ws[key].numel() < 64 * cols:
         _ws[key] = torch.empty(64 * max(cols, 4096), dtype=torch.float64, device=x.device)
     ws = _ws[key]
-    _lib.check(_lib.lib().mla_col_sum(_p(x), x.stride(0), rows, cols, _p(ws), _p(out), _lib.stream_ptr()))
+    fn = _lib.lib().mla_col_sum_bf16 if x.dtype == torch.bfloat16 else _lib.lib().mla_col_sum
+    _lib.check(fn(_p(x), x.stride(0), rows, cols, _p(ws), _p(out), _lib.stream_ptr()))
     return out
 
 
@@ -435,38 +442,50 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
 # ------------------------------------------------------------------ finetune (CNN gradients) ----
 
 def conv3x3(x, w_packed, b, cout, pool, act):
-    """Generic f32 conv entry (training forward without fused pool, and dgrad). x NHWC."""
-    _chk(x, torch.float32); _chk(w_packed, torch.float32)
+    """Generic conv entry (training forward without fused pool, and dgrad), f32 or bf16. x NHWC."""
+    _chk(x); _chk(w_packed, x.dtype)
     n, H, W_, cin = x.shape
-    out = torch.empty((n, H // 2, W_ // 2, cout) if pool else (n, H, W_, cout), dtype=torch.float32, device=x.device)
+    out = torch.empty((n, H // 2, W_ // 2, cout) if pool else (n, H, W_, cout), dtype=x.dtype, device=x.device)
     _lib.check(_timed("conv3x3_%d_%d" % (cin, cout), _lib.lib().mla_conv3x3, _p(x), _p(w_packed), _p(b), _p(out), n, H, W_, cin, cout,
-                      int(pool), int(act), _lib.F32, _lib.stream_ptr()))
+                      int(pool), int(act), DT[x.dtype], _lib.stream_ptr()))
     return out
 
 
-def repack_dgrad(w):
-    """(Cout, Cin, 3, 3) -> (Cin, 9, Cout) flipped: weights of the transposed convolution."""
+def repack_dgrad(w, dtype=torch.float32):
+    """(Cout, Cin, 3, 3) f32 -> (Cin, 9, Cout) flipped, in `dtype`: weights of the transposed convolution."""
     _chk(w, torch.float32)
     cout, cin = w.shape[0], w.shape[1]
-    out = torch.empty((cin, 9, cout), dtype=torch.float32, device=w.device)
-    _lib.check(_lib.lib().mla_conv_repack_dgrad(_p(w), cout, cin, _p(out), _lib.stream_ptr()))
+    out = torch.empty((cin, 9, cout), dtype=dtype, device=w.device)
+    fn = _lib.lib().mla_conv_repack_dgrad_bf16 if dtype == torch.bfloat16 else _lib.lib().mla_conv_repack_dgrad
+    _lib.check(fn(_p(w), cout, cin, _p(out), _lib.stream_ptr()))
     return out
 
 
 def maxpool2x2(a):
-    _chk(a, torch.float32)
+    _chk(a)
     n, H, W_, C = a.shape
-    out = torch.empty((n, H // 2, W_ // 2, C), dtype=torch.float32, device=a.device)
-    _lib.check(_lib.lib().mla_maxpool2x2(_p(a), _p(out), n, H, W_, C, _lib.stream_ptr()))
+    out = torch.empty((n, H // 2, W_ // 2, C), dtype=a.dtype, device=a.device)
+    fn = _lib.lib().mla_maxpool2x2_bf16 if a.dtype == torch.bfloat16 else _lib.lib().mla_maxpool2x2
+    _lib.check(_timed("maxpool", fn, _p(a), _p(out), n, H, W_, C, _lib.stream_ptr()))
     return out
 
 
-def relu_pool_bwd(a, d_out, pool, db=None):
+def relu_pool_bwd(a, d_out, pool, db=None, bf16=False):
     """dZ at a's resolution from the gradient of relu(.) [pool == 0] or maxpool(relu(.)) [pool == 1]; db (C,): also the
-    bias gradient = column sums of dZ, accumulated in the same pass."""
-    _chk(a, torch.float32); _chk(d_out, torch.float32)
+    bias gradient = column sums of dZ, accumulated in the same pass. bf16 (or a bf16 `a`): dZ in bf16 (a / d_out both bf16,
+    or both f32 for the last Linear whose output is f32)."""
+    _chk(a); _chk(d_out, a.dtype)
     a4 = a if a.dim() == 4 else a.reshape(a.shape[0], 1, 1, -1)
     n, H, W_, C = a4.shape
+    if bf16 or a.dtype == torch.bfloat16:
+        dz = torch.empty(a.shape, dtype=torch.bfloat16, device=a.device)
+        key = "biasws16/" + str(a.device)
+        if key not in _ws:
+            _ws[key] = torch.empty(int(_lib.lib().mla_relu_pool_bwd_bf16_workspace_bytes()) // 8, dtype=torch.float64, device=a.device)
+        _lib.check(_timed("relu_pool_bwd", _lib.lib().mla_relu_pool_bwd_bf16, _p(a), DT[a.dtype], _p(d_out), DT[d_out.dtype], _p(dz), n, H, W_, C,
+                          int(pool), _p(_ws[key]), _p(db), _lib.stream_ptr()))
+        return dz
+    _chk(a, torch.float32)
     dz = torch.empty_like(a)
     if db is None:
         _lib.check(_lib.lib().mla_relu_pool_bwd(_p(a), _p(d_out), _p(dz), n, H, W_, C, int(pool), _lib.stream_ptr()))
@@ -475,7 +494,8 @@ def relu_pool_bwd(a, d_out, pool, db=None):
     key = "biasws/" + str(a.device)
     if key not in _ws:
         _ws[key] = torch.empty(int(_lib.lib().mla_relu_pool_bwd_bias_workspace_bytes()) // 8, dtype=torch.float64, device=a.device)
-    _lib.check(_lib.lib().mla_relu_pool_bwd_bias(_p(a), _p(d_out), _p(dz), n, H, W_, C, int(pool), _p(_ws[key]), _p(db), _lib.stream_ptr()))
+    _lib.check(_timed("relu_pool_bwd", _lib.lib().mla_relu_pool_bwd_bias, _p(a), _p(d_out), _p(dz), n, H, W_, C, int(pool), _p(_ws[key]), _p(db),
+                      _lib.stream_ptr()))
     return dz
 
 
@@ -483,20 +503,21 @@ _wg_ws = {}
 
 
 def conv_wgrad(dz, a_in, dw):
-    _chk(dz, torch.float32); _chk(a_in, torch.float32)
+    _chk(dz); _chk(a_in, dz.dtype)
     n, H, W_, cout = dz.shape
     cin = a_in.shape[3]
     key = str(dz.device)
     if key not in _wg_ws:
         _wg_ws[key] = torch.empty(int(_lib.lib().mla_conv_wgrad_workspace_floats()), dtype=torch.float32, device=dz.device)
     ws = _wg_ws[key]
-    assert dw.is_contiguous() and tuple(dw.shape) == (cout, cin, 3, 3)
-    _lib.check(_timed("wgrad_%d_%d" % (cin, cout), _lib.lib().mla_conv_wgrad, _p(dz), _p(a_in), n, H, W_, cin, cout, _p(ws), ws.numel(),
-                      _p(dw), _lib.stream_ptr()))
+    assert dw.is_contiguous() and tuple(dw.shape) == (cout, cin, 3, 3) and dw.dtype == torch.float32
+    fn = _lib.lib().mla_conv_wgrad_bf16 if dz.dtype == torch.bfloat16 else _lib.lib().mla_conv_wgrad
+    _lib.check(_timed("wgrad_%d_%d" % (cin, cout), fn, _p(dz), _p(a_in), n, H, W_, cin, cout, _p(ws), ws.numel(), _p(dw), _lib.stream_ptr()))
 
 
 def conv1_bwd(x, w, b, d_pooled, dw, db):
-    _chk(x, torch.float32); _chk(d_pooled, torch.float32)
+    _chk(x, torch.float32); _chk(d_pooled)
     n = x.shape[0]
     ws = torch.empty(1024 * 8 * 80, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().mla_conv1_bwd(_p(x), _p(w), _p(b), _p(d_pooled), n, _p(ws), _p(dw), _p(db), _lib.stream_ptr()))
+    fn = _lib.lib().mla_conv1_bwd_bf16 if d_pooled.dtype == torch.bfloat16 else _lib.lib().mla_conv1_bwd
+    _lib.check(_timed("conv1_bwd", fn, _p(x), _p(w), _p(b), _p(d_pooled), n, _p(ws), _p(dw), _p(db), _lib.stream_ptr()))

@@ -134,7 +134,7 @@ class TrainStep:
         with torch.no_grad():
             x = clf.input(inputs)
             if self.finetune:
-                feats, cnn_tape = cnn_train.forward(clf.cnn.cnn_model, x)
+                feats, cnn_tape = cnn_train.forward(clf.cnn.cnn_model, x, clf.cnn.precision)
             else:
                 feats = clf.cnn(x)
             ctx = mla_train.Ctx(tape=True, dist=self.dist)

@@ -267,7 +267,8 @@ int mla_cross_entropy(const float* x, int64_t ldx, const int64_t* labels, int64_
 
 /* Generic 3x3/pad-1 convolution entry over the compiled shape set (VGGish forward with or
  * without the fused 2x2 pool, and the five dgrad shapes): act != 0 -> bias + ReLU epilogue,
- * act == 0 -> plain store (transposed convolution; bias may be NULL). f32 only. */
+ * act == 0 -> plain store (transposed convolution; bias may be NULL). dtype MLA_F32 or MLA_BF16
+ * (activations and repacked weights in that type, f32 accumulation). */
 int mla_conv3x3(const void* in, const void* w_packed, const float* bias, void* out, int64_t n, int H, int W,
                 int cin, int cout, int pool, int act, int dtype, mla_stream_t stream);
 /* (Cout, Cin, 3, 3) -> (Cin, 9, Cout), taps flipped: weights of the dgrad convolution. */
@@ -293,6 +294,26 @@ int mla_conv_wgrad(const float* dz, const float* a_in, int64_t n, int H, int W, 
  * dw (64,1,3,3), db (64). workspace: 1024*8*80 floats. */
 int mla_conv1_bwd(const float* x, const float* w, const float* bias, const float* d_pooled, int64_t n, float* workspace,
                   float* dw, float* db, mla_stream_t stream);
+
+/* --- the same backward in bf16 (activations and gradients bf16, f32 accumulation, f32 weight / bias gradients):
+ *     what the finetune step runs in at speed; weights stay f32 masters, bf16 copies are re-derived after each Adam step --- */
+int mla_conv_repack_dgrad_bf16(const float* w_oihw, int64_t cout, int64_t cin, void* out_bf16, mla_stream_t stream);
+int mla_maxpool2x2_bf16(const void* a, void* out, int64_t n, int H, int W, int C, mla_stream_t stream);
+/* dZ (bf16) as mla_relu_pool_bwd; a / d_out both bf16 or both f32 (the last Linear's f32 output). db != NULL: also the bias
+ * gradient (column sums of dZ, double-precision partials in `workspace` of mla_relu_pool_bwd_bf16_workspace_bytes()). */
+int64_t mla_relu_pool_bwd_bf16_workspace_bytes(void);
+int mla_relu_pool_bwd_bf16(const void* a, int a_dtype, const void* d_out, int d_dtype, void* dz, int64_t n, int H, int W,
+                           int C, int pool, void* workspace, float* db, mla_stream_t stream);
+/* dW f32 (Cout, Cin, 3, 3) from bf16 dZ and bf16 a_in on v_mfma_f32_16x16x32_bf16 (operands through the transposing LDS
+ * read ds_read_b64_tr_b16); workspace as mla_conv_wgrad. */
+int mla_conv_wgrad_bf16(const void* dz, const void* a_in, int64_t n, int H, int W, int cin, int cout, float* workspace,
+                        int64_t workspace_floats, float* dw_oihw, mla_stream_t stream);
+int mla_conv1_bwd_bf16(const float* x, const float* w, const float* bias, const void* d_pooled_bf16, int64_t n, float* workspace,
+                       float* dw, float* db, mla_stream_t stream);
+/* (rows, cols) bf16 -> (cols, ld_out >= rows) bf16, the padding columns zeroed: K-contiguous operands of the Linear backward */
+int mla_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int64_t cols, mla_stream_t stream);
+/* column sums of a bf16 (rows, cols) matrix -> f32 (bias gradient of a Linear); workspace: 64 * cols doubles */
+int mla_col_sum_bf16(const void* x, int64_t ldx, int64_t rows, int64_t cols, void* workspace, float* out, mla_stream_t stream);
 
 /* torch.optim.Adam step t (train.py:369; no weight decay, no amsgrad) over one flat buffer. */
 int mla_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

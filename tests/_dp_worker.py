@@ -18,13 +18,14 @@ PKG = "audio-classification-using-a-deep-cnn-combined-with-multi-level-attention
 
 def main():
     out_path, steps, B = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    precision = sys.argv[4] if len(sys.argv) > 4 else "f32"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     mk = importlib.import_module("make_golden")
     W = importlib.import_module(PKG + ".weights")
     M = importlib.import_module(PKG + ".model")
     TR = importlib.import_module(PKG + ".train")
-    ens = M.Ensemble("repeat", dict(mk.CNN_CONF), [2, 1], torch.device("cuda"))
+    ens = M.Ensemble("repeat", dict(mk.CNN_CONF), [2, 1], torch.device("cuda"), precision=precision)
     ens.load_state_dict({k: torch.as_tensor(v) for k, v in W.make_state_dict(7, W.ensemble_shapes((2, 1), False)).items()})
     ens.cuda()
     step = TR.TrainStep(ens, lr=1e-3)

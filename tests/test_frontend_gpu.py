@@ -202,3 +202,33 @@ def test_waveform_to_examples_never_rescales_integer_input(vi, W):
             assert np.abs(got - ref).max() <= 1e-4
     scaled = ofe.waveform_to_examples(i16[:, 0] / 32768.0)
     assert np.abs(ofe.waveform_to_examples(i16[:, 0].astype(np.float64)) - scaled).mean() > 5.0   # the two readings differ by ~ln(32768)
+
+
+def test_config2_literal_shapes_against_the_oracle(fe, vi, W):
+    """BASELINE config 2 at its literal sizes ("256 x 0.96 s frames"), both ways of reading it, through mla_logmel_examples
+    and checked value by value against the oracle (256 examples of numpy f64 work: well under a second):
+      (a) ONE waveform of 256 x 15 360 + 240 = 3 932 400 samples -> 256 examples (the framing walks one long row);
+      (b) 256 waveforms of 15 600 samples (the shortest input that yields one example) -> 256 examples, one per row."""
+    n_long = 256 * 15360 + 240
+    long = W.waveform(51, n_long, 1, dtype=np.float64)[0]
+    assert fe.counts(n_long) == (24576, 256)
+    got = vi.waveform_to_examples(long, 16000, return_tensor=False)
+    ref = ofe.waveform_to_examples(long)
+    assert got.shape == ref.shape == (256, 96, 64)
+    assert np.abs(got - ref).max() <= 1e-4
+    # the same through the batched entry, f32 and bf16 outputs, PCM as int16 too
+    pcm = torch.from_numpy(long.astype(np.float32)).cuda()[None]
+    ex = fe.waveforms_to_examples(pcm)
+    assert np.array_equal(ex.cpu().numpy(), got.astype(np.float32))
+    exb = fe.waveforms_to_examples(pcm, out_dtype=torch.bfloat16)
+    assert torch.equal(exb, ex.to(torch.bfloat16))                                 # one rounding of the f32 result
+
+    rows = W.waveform(52, 15600, 256, dtype=np.float64)
+    assert fe.counts(15600) == (96, 1)
+    got = fe.waveforms_to_examples(torch.from_numpy(rows.astype(np.float32)).cuda()).cpu().numpy()
+    ref = ofe.batch_examples(rows)
+    assert got.shape == ref.shape == (256, 96, 64)
+    assert np.abs(got - ref).max() <= 1e-4
+    i16 = np.round(rows * 20000).astype(np.int16)
+    got16 = fe.waveforms_to_examples(torch.from_numpy(i16).cuda()).cpu().numpy()    # PCM path: 1/32768 in the kernel's read
+    assert np.abs(got16 - ofe.batch_examples(i16 / 32768.0)).max() <= 1e-4

@@ -337,3 +337,56 @@ def test_dropout_mask_stream_is_the_portable_generator(W):
     assert torch.equal(d2.keep_mask(5000, torch.device("cuda")), a)
     d2.mask = torch.ones(5000, dtype=torch.uint8)
     assert bool(d2.keep_mask(5000, torch.device("cuda")).all())                 # an injected mask wins
+
+
+def test_config4_full_size_step_is_deterministic_and_shards_exactly(tmp_path, mk, W):
+    """BASELINE config 4 at its literal size: train.py's step on 512 bags (5 120 clips of 96 x 64 log-mel), frozen CNN in
+    bf16 (the bench's configuration). The CPU reference cannot run this in seconds, so size-independent properties:
+    (1) two runs give identical bits (losses, every updated parameter, running statistics);
+    (2) two ranks with 256 bags each (gloo, sharing the test GPU) stay bit-identical replicas of each other and reproduce
+        the one-process run on the global batch: losses to 2e-6 relative, updated parameters to float32 rounding of the
+        different summation tree (the SyncBN sums and the gradient are added rank by rank instead of in one pass)."""
+    TR = importlib.import_module(PKG + ".train")
+    M = importlib.import_module(PKG + ".model")
+    B, steps = 512, 2
+
+    def one_process():
+        ens = M.Ensemble("repeat", dict(mk.CNN_CONF), [2, 1], torch.device("cuda"), precision="bf16")
+        ens.load_state_dict({k: torch.as_tensor(v) for k, v in W.make_state_dict(7, W.ensemble_shapes((2, 1), False)).items()})
+        ens.cuda()
+        step = TR.TrainStep(ens, lr=1e-3)
+        losses = []
+        for s in range(steps):
+            x, y = mk.synth_bags(100 + s, B)
+            install(ens, mk.make_masks(200 + s, [2, 1], B))
+            loss, hits = step(x.cuda(), y.cuda())
+            losses.append(float(loss))
+            assert 0 <= int(hits) <= B
+        return losses, {k: v.detach().cpu().numpy() for k, v in ens.state_dict().items() if k.startswith("mla.")}
+
+    l1, sd1 = one_process()
+    l2, sd2 = one_process()
+    assert l1 == l2 and all(np.array_equal(sd1[k], sd2[k]) for k in sd1), "the step must be bit-deterministic"
+    assert all(np.isfinite(l1)) and abs(l1[0] - np.log(10.0)) < 0.2              # 10 classes, untrained head
+
+    out = str(tmp_path / "dp512")
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_worker.py"), out, str(steps), str(B), "bf16"],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    r0, r1 = np.load(out + ".rank0.npz"), np.load(out + ".rank1.npz")
+    for k in r0.files:
+        np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)                    # replicas: bit-identical
+    np.testing.assert_allclose(r0["losses"], l1, rtol=2e-6, atol=0)
+    worst = 0.0
+    for k in sd1:
+        if k.endswith(NOISY) or "num_batches" in k:
+            continue
+        a, b = r0[k].astype(np.float64), sd1[k].astype(np.float64)
+        scale = max(np.abs(b).max(), 1e-3)
+        worst = max(worst, np.abs(a - b).max() / scale)
+        # Adam's first steps are +-lr whatever the gradient's size: a last-bit difference in a near-zero gradient flips a sign
+        # (2 steps x lr 1e-3 against weights of ~0.05); everything else agrees to float32 rounding
+        np.testing.assert_allclose(a, b, rtol=0, atol=5e-3 * scale + 4.1e-3, err_msg=k)
+    print("config 4, 2 ranks vs 1 process: worst parameter deviation %.3g of the tensor's scale" % worst)
