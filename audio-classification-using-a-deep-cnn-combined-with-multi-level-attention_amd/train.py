@@ -94,13 +94,26 @@ class TrainStep:
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grads, self._seated, off = {}, [], 0
+        spans = {}                                        # bucket id -> [first float, one past the last] of the flat buffers
         for n, p in named:
             k = p.numel()
             self.flat_p[off:off + k].copy_(p.detach().reshape(-1))
             p.data = self.flat_p[off:off + k].view(p.shape)
             self.grads[n] = self.flat_g[off:off + k].view(p.shape)
             self._seated.append((n, p, self.flat_p.data_ptr() + 4 * off))
+            b = self._bucket_of(n)
+            spans[b] = [min(spans.get(b, [off, 0])[0], off), off + pad4(k)]
             off += pad4(k)
+        # Gradient buckets of the data-parallel exchange: contiguous ranges of the flat gradient buffer that become final
+        # at known points of the backward pass -- the head first, then the CNN from its last Linear down to conv1 -- so that
+        # each range can be all-reduced on a second HIP stream while the layers below are still computing (the parameters
+        # are laid out in named_parameters() order = forward order, so "the layers from position p upwards" is one range):
+        #   "mla" 3.2 MB | "fc12" embeddings.2 + .4: 69 MB | "fc0" embeddings.0: 201 MB | "conv56" 14 MB | "conv14" 4 MB
+        # xGMI rings are per-link bound, so a few large messages beat many small ones; the order above is the order in which
+        # the backward pass finishes them.
+        self.buckets = {b: tuple(v) for b, v in spans.items()}
+        self.overlap = os.environ.get("MLA_DIST_OVERLAP", "1") == "1"
+        self._comm_stream = None
         # MLA parameters outside the update set still need somewhere to write their gradient (the head's backward always
         # runs whole: it is 0.3 ms); those scratch tensors are never read
         self.mla_grads = {}
@@ -108,6 +121,30 @@ class TrainStep:
             if ".fcf." in n:
                 continue
             self.mla_grads[n] = self.grads["mla." + n] if "mla." + n in self.grads else torch.empty_like(p, dtype=torch.float32, device=dev)
+
+    # layer position (cnn_train.backward's `pos`: 0..5 conv1..conv6, 6..8 the three Linear layers) at which a bucket is final
+    BUCKET_TRIGGER = {"fc12": 7, "fc0": 6, "conv56": 4, "conv14": 0}
+
+    @staticmethod
+    def _bucket_of(name):
+        if not name.startswith("cnn."):
+            return "mla"
+        key = name.split(".")[-3:-1]                      # (..., "features" | "embeddings" | "0", index, "weight" | "bias")
+        idx = int(key[1])
+        if key[0] == "embeddings":
+            return "fc0" if idx == 0 else "fc12"
+        return "conv56" if idx >= 11 else "conv14"
+
+    def _reduce_bucket(self, name):
+        """All-reduce one finished gradient range on the communication stream (it first waits for the compute stream's work
+        enqueued so far, i.e. for the kernels that produced the range)."""
+        a, b = self.buckets[name]
+        cur = torch.cuda.current_stream()
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=self.flat_g.device)
+        self._comm_stream.wait_stream(cur)
+        with torch.cuda.stream(self._comm_stream):
+            self.dist.all_reduce_sum(self.flat_g[a:b])
 
     def state_dict(self):
         """Optimizer state as plain tensors (Adam moments over the flat buffer + step count): what
@@ -142,10 +179,28 @@ class TrainStep:
             ops.check_labels(labels, out.shape[1])
             loss, dout, hits = ops.cross_entropy(out, labels.to(out.device).long().contiguous(), 1.0 / B_global)
             d_feats = mla_train.mla_backward(clf.mla, ctx, dout, self.mla_grads, need_input_grad=self.finetune)
-            if self.finetune:
+            bucketed = self.dist.active and self.finetune and self.overlap
+            if bucketed:
+                # the head's gradients are final: reduce them while the CNN backward runs; each CNN bucket follows as soon as
+                # the lowest layer it holds is done. No other collective is issued until the compute stream has waited for
+                # the communication stream below, so the two streams never use the communicator at the same time.
+                pending = [b for b in ("mla", "fc12", "fc0", "conv56", "conv14") if b in self.buckets]
+                if "mla" in pending:
+                    self._reduce_bucket("mla"); pending.remove("mla")
+
+                def after_layer(pos):
+                    for b in list(pending):
+                        if self.BUCKET_TRIGGER[b] == pos:
+                            self._reduce_bucket(b); pending.remove(b)
+                cnn_train.backward(clf.cnn.cnn_model, cnn_tape, d_feats, self.grads, "cnn.cnn_model.", after_layer)
+                for b in pending:                          # buckets whose trigger layer lies below the lowest trained layer
+                    self._reduce_bucket(b)
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
+            elif self.finetune:
                 cnn_train.backward(clf.cnn.cnn_model, cnn_tape, d_feats, self.grads, "cnn.cnn_model.")
             if self.dist.active:
-                self.dist.all_reduce_sum(self.flat_g)
+                if not bucketed:
+                    self.dist.all_reduce_sum(self.flat_g)
                 self.dist.all_reduce_sum(loss)
                 self.dist.all_reduce_sum(hits)             # running_corrects (train.py:142) over the global batch
             self.t += 1

@@ -19,6 +19,7 @@ PKG = "audio-classification-using-a-deep-cnn-combined-with-multi-level-attention
 def main():
     out_path, steps, B = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     precision = sys.argv[4] if len(sys.argv) > 4 else "f32"
+    finetune = len(sys.argv) > 5 and sys.argv[5] == "finetune"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     mk = importlib.import_module("make_golden")
@@ -28,6 +29,8 @@ def main():
     ens = M.Ensemble("repeat", dict(mk.CNN_CONF), [2, 1], torch.device("cuda"), precision=precision)
     ens.load_state_dict({k: torch.as_tensor(v) for k, v in W.make_state_dict(7, W.ensemble_shapes((2, 1), False)).items()})
     ens.cuda()
+    if finetune:
+        M.set_requires_grad(ens, True)             # every parameter trainable: the gradient buckets travel while the CNN backward runs
     step = TR.TrainStep(ens, lr=1e-3)
     lo, hi = rank * B // world, (rank + 1) * B // world
     losses = []
@@ -39,7 +42,7 @@ def main():
                 d.mask = masks["mla.embedded_mappings.%d.dropouts.%d" % (lvl, j)][lo:hi]
         loss, hits = step(x[lo:hi].cuda(), y[lo:hi].cuda())
         losses.append(float(loss))
-    sd = {k: v.detach().cpu().numpy() for k, v in ens.state_dict().items() if k.startswith("mla.")}
+    sd = {k: v.detach().cpu().numpy() for k, v in ens.state_dict().items() if k.startswith("mla.") or (finetune and k.endswith(".bias"))}
     np.savez(out_path + ".rank%d.npz" % rank, losses=np.array(losses), **sd)
     dist.barrier()
     dist.destroy_process_group()

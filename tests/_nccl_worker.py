@@ -26,6 +26,11 @@ def run_steps(mk, W, M, TR, always, finetune):
         M.set_requires_grad(ens, True)
     step = TR.TrainStep(ens, lr=1e-3)
     assert step.dist.active == always
+    if finetune:                                   # the five gradient buckets tile the flat buffer, in forward order
+        spans = sorted(step.buckets.values())
+        assert set(step.buckets) == {"mla", "conv14", "conv56", "fc0", "fc12"} and spans[0][0] == 0 and spans[-1][1] == step.flat_g.numel()
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert [k for k, _ in sorted(step.buckets.items(), key=lambda kv: kv[1])] == ["mla", "conv14", "conv56", "fc0", "fc12"]
     losses, hits = [], []
     for s in range(3):
         x, y = mk.synth_bags(100 + s, 4)
@@ -71,9 +76,11 @@ def main():
         print("nccl worker: %s transport ok, losses %s" % (via, coll[0]))
     os.environ["MLA_DIST_COLLECTIVE"] = "abi"
     base = run_steps(mk, W, M, TR, False, True)
-    coll = run_steps(mk, W, M, TR, True, True)
-    assert base[0] == coll[0] and torch.equal(base[2], coll[2])
-    print("nccl worker: finetune step over the C-ABI all-reduce ok")
+    for overlap in ("1", "0"):                     # bucketed reductions on the communication stream / one flat all-reduce at the end
+        os.environ["MLA_DIST_OVERLAP"] = overlap
+        coll = run_steps(mk, W, M, TR, True, True)
+        assert base[0] == coll[0] and torch.equal(base[2], coll[2]), overlap
+    print("nccl worker: finetune step over the C-ABI all-reduce ok (bucketed + overlapped, and flat)")
     dist.barrier()
     dist.destroy_process_group()
     print("nccl worker ok")

@@ -390,3 +390,22 @@ def test_config4_full_size_step_is_deterministic_and_shards_exactly(tmp_path, mk
         # (2 steps x lr 1e-3 against weights of ~0.05); everything else agrees to float32 rounding
         np.testing.assert_allclose(a, b, rtol=0, atol=5e-3 * scale + 4.1e-3, err_msg=k)
     print("config 4, 2 ranks vs 1 process: worst parameter deviation %.3g of the tensor's scale" % worst)
+
+
+def test_two_ranks_finetune_with_bucketed_gradient_exchange(tmp_path, golden):
+    """Finetune under data parallelism: the flat gradient buffer travels as five buckets on a second stream while the CNN
+    backward is still running (TrainStep._reduce_bucket). Two ranks with 2 bags each (gloo, sharing the test GPU) reproduce
+    the reference's 4-bag finetune run and stay bit-identical replicas, CNN biases included."""
+    g = golden("train")
+    out = str(tmp_path / "dpft")
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29523", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_worker.py"), out, "3", "4", "f32", "finetune"],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    r0, r1 = np.load(out + ".rank0.npz"), np.load(out + ".rank1.npz")
+    np.testing.assert_allclose(r0["losses"][:1], g["finetune/losses"][:1], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(r0["losses"], g["finetune/losses"][:3], rtol=2e-3, atol=1e-5)
+    assert any(k.startswith("cnn.") for k in r0.files)
+    for k in r0.files:
+        np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
