@@ -97,6 +97,9 @@ def lib():
         L.mla_conv1_bwd_bf16.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp]
         L.mla_transpose_bf16.argtypes = [vp, i64, vp, i64, i64, i64, vp]
         L.mla_col_sum_bf16.argtypes = [vp, i64, i64, i64, vp, vp, vp]
+        L.mla_resample_length.restype = i64
+        L.mla_resample_length.argtypes = [i64, cd, cd]
+        L.mla_resample.argtypes = [vp, i64, cd, cd, vp, vp, ci, ci, vp, i64, vp]
         u64 = ctypes.c_uint64
         L.mla_dropout_mask.argtypes = [vp, i64, u64, u64, u64, cf, vp]
         L.mla_comm_unique_id.argtypes = [vp]

@@ -151,6 +151,68 @@ __global__ __launch_bounds__(256) void mono_mix_kernel(const T* __restrict__ pcm
     out[i] = float(acc / double(channels) * scale);
 }
 
+// ---- resampling to 16 kHz (vggish_input.py:52-53: resampy.resample(data, sample_rate, 16000), filter 'kaiser_best') ----
+// Band-limited sinc interpolation (J. O. Smith) as resampy/interpn.py runs it: output sample t sits at input time
+// t / ratio; it is the inner product of the input with the Kaiser-windowed sinc centred there, the filter read from a table of
+// `num_table` entries per zero crossing with linear interpolation between entries (win + eta * delta), left wing over
+// x[n], x[n-1], ..., right wing over x[n+1], x[n+2], ...; for ratio < 1 the table is stepped by int(ratio * num_table) entries per
+// input sample (the time-stretched, gain-scaled low-pass). One lane per output sample; the ~2 * 64 / min(1, ratio) taps of a
+// lane read consecutive input samples (L1/L2-resident: neighbouring lanes share all but one) and a table that fits L2 (512 KB
+// in double precision). Double accumulation like the reference's float64 arrays; latency-bound, not a roofline kernel
+// (a 10 s clip at 44.1 kHz is 160 000 outputs x 354 taps = 57 MFMA-free MFLOP).
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, int64_t n_in, const double* __restrict__ win,
+                                                       const double* __restrict__ delta, int nwin, int num_table, double ratio,
+                                                       float* __restrict__ y, int64_t n_out) {
+    const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= n_out) return;
+    const double scale = ratio < 1.0 ? ratio : 1.0;
+    const int index_step = int(scale * num_table);
+    const double treg = double(t) * (1.0 / ratio);
+    const int64_t n = int64_t(treg);
+    double acc = 0.0;
+    double frac = scale * (treg - double(n));
+    double index_frac = frac * num_table;
+    int offset = int(index_frac);
+    double eta = index_frac - offset;
+    int64_t i_max = (nwin - offset) / index_step;
+    if (n + 1 < i_max) i_max = n + 1;
+    for (int64_t i = 0; i < i_max; ++i) {
+        const int idx = offset + int(i) * index_step;
+        acc += (win[idx] + eta * delta[idx]) * double(x[n - i]);
+    }
+    frac = scale - frac;
+    index_frac = frac * num_table;
+    offset = int(index_frac);
+    eta = index_frac - offset;
+    int64_t k_max = (nwin - offset) / index_step;
+    if (n_in - n - 1 < k_max) k_max = n_in - n - 1;
+    for (int64_t k = 0; k < k_max; ++k) {
+        const int idx = offset + int(k) * index_step;
+        acc += (win[idx] + eta * delta[idx]) * double(x[n + k + 1]);
+    }
+    y[t] = float(acc);
+}
+
+extern "C" int64_t mla_resample_length(int64_t n_in, double sr_in, double sr_out) {
+    if (n_in < 0 || !(sr_in > 0.0) || !(sr_out > 0.0)) return -1;
+    return int64_t(double(n_in) * (sr_out / sr_in));
+}
+
+extern "C" int mla_resample(const float* x, int64_t n_in, double sr_in, double sr_out, const double* win, const double* delta,
+                            int nwin, int num_table, float* y, int64_t n_out, mla_stream_t stream) {
+    MLA_REQUIRE(sr_in > 0.0 && sr_out > 0.0 && n_in >= 0 && nwin > 1 && num_table > 0, MLA_E_ARG, "bad resample arguments");
+    MLA_REQUIRE(n_out == mla_resample_length(n_in, sr_in, sr_out), MLA_E_SHAPE, "n_out %lld != int(n_in * sr_out / sr_in) = %lld",
+                (long long)n_out, (long long)mla_resample_length(n_in, sr_in, sr_out));
+    MLA_REQUIRE(n_out >= 1, MLA_E_SHORT, "input of %lld samples is too short to resample from %g to %g Hz", (long long)n_in, sr_in, sr_out);
+    const double ratio = sr_out / sr_in;
+    MLA_REQUIRE(int((ratio < 1.0 ? ratio : 1.0) * num_table) >= 1, MLA_E_SHAPE, "ratio %g is below the filter table's resolution", ratio);
+    MLA_REQUIRE(x && win && delta && y, MLA_E_ARG, "null resample buffers");
+    hipLaunchKernelGGL(resample_kernel, dim3(unsigned((n_out + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, n_in, win,
+                       delta, nwin, num_table, ratio, y, n_out);
+    MLA_LAUNCH_OK("resample_kernel");
+    return MLA_OK;
+}
+
 extern "C" int mla_mono_mix(const void* pcm, int pcm_dtype, int64_t n_samples, int channels, float* out, mla_stream_t stream) {
     MLA_REQUIRE(n_samples >= 0 && channels >= 1, MLA_E_ARG, "bad n_samples %lld / channels %d", (long long)n_samples, channels);
     MLA_REQUIRE(pcm_dtype == MLA_F32 || pcm_dtype == MLA_I16, MLA_E_DTYPE, "pcm_dtype %d", pcm_dtype);

@@ -72,6 +72,52 @@ def as_device_mono(data, pcm16=False):
     return out
 
 
+_resample_tables = {}
+
+
+def kaiser_best_filter():
+    """resampy's default interpolation filter 'kaiser_best' (resampy/filters.py sinc_window: 64 zero crossings, 2**9 table entries
+    per crossing, Kaiser beta 14.769656459379492, rolloff 0.9475937167399596), right half, float64. resampy ships this table as a
+    data file; it is host-side setup like the mel matrix. (interp_win, num_table)."""
+    num_zeros, precision, beta, rolloff = 64, 9, 14.769656459379492, 0.9475937167399596
+    num_bits = 2 ** precision
+    n = num_bits * num_zeros
+    sinc_win = rolloff * np.sinc(rolloff * np.linspace(0, num_zeros, num=n + 1, endpoint=True))
+    return np.kaiser(2 * n + 1, beta)[n:] * sinc_win, num_bits
+
+
+def resample(wave, sr_orig, sr_new, gain=1.0):
+    """resampy.resample(wave, sr_orig, sr_new) (vggish_input.py:52-53) for a 1-D device waveform -> float32 device tensor of
+    int(n * sr_new / sr_orig) samples, by the HIP kernel mla_resample (`gain` scales the filter table: the operation is linear).
+    ValueError where resampy raises (bad rates, empty result)."""
+    if sr_orig <= 0:
+        raise ValueError("Invalid sample rate: sr_orig=%r" % (sr_orig,))
+    if sr_new <= 0:
+        raise ValueError("Invalid sample rate: sr_new=%r" % (sr_new,))
+    assert wave.dim() == 1 and wave.is_cuda
+    wave = wave.float().contiguous()
+    ratio = float(sr_new) / float(sr_orig)
+    L = _lib.lib()
+    n_out = int(L.mla_resample_length(wave.shape[0], float(sr_orig), float(sr_new)))
+    if n_out < 1:
+        raise ValueError("Input signal length=%d is too small to resample from %s->%s" % (wave.shape[0], sr_orig, sr_new))
+    key = (str(wave.device), ratio if ratio < 1 else 1.0, float(gain))
+    if key not in _resample_tables:
+        win, num_table = kaiser_best_filter()
+        if ratio < 1:
+            win = win * ratio
+        win = win * float(gain)
+        delta = np.zeros_like(win)
+        delta[:-1] = np.diff(win)
+        _resample_tables[key] = (torch.from_numpy(win).to(wave.device), torch.from_numpy(delta).to(wave.device), num_table)
+    win, delta, num_table = _resample_tables[key]
+    out = torch.empty(n_out, dtype=torch.float32, device=wave.device)
+    vp = ctypes.c_void_p
+    _lib.check(L.mla_resample(vp(wave.data_ptr()), wave.shape[0], float(sr_orig), float(sr_new), vp(win.data_ptr()), vp(delta.data_ptr()),
+                              win.shape[0], num_table, vp(out.data_ptr()), n_out, _lib.stream_ptr()))
+    return out
+
+
 def waveforms_to_examples(pcm, out_dtype=torch.float32, out=None):
     """(W, n) device PCM (float32 or int16) -> (W * N, 96, 64) examples, waveform-major."""
     assert pcm.dim() == 2 and pcm.is_cuda and pcm.stride(1) == 1

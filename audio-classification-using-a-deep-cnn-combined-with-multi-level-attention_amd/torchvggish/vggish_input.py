@@ -23,11 +23,14 @@ def waveform_to_examples(data, sample_rate, return_tensor=True, _pcm16=False):
     or, with ``return_tensor=False``, an ``(N, 96, 64)`` float64 ndarray like the reference.
     """
     if sample_rate != vggish_params.SAMPLE_RATE:
-        # vggish_input.py:52-53 resamples with resampy; that branch is outside the hot path
-        # (SURVEY.md section 8f, f3) and resampy is not available -> refuse rather than guess.
-        raise NotImplementedError("only %d Hz input is supported on the HIP path (got %r)"
-                                  % (vggish_params.SAMPLE_RATE, sample_rate))
-    examples = frontend.waveforms_to_examples(frontend.as_device_mono(data, pcm16=_pcm16)[None], out_dtype=torch.float32)
+        # vggish_input.py:52-53: resampy.resample(data, sample_rate, 16000) -- band-limited sinc interpolation with resampy's
+        # 'kaiser_best' filter, as a HIP kernel. resampy is not installed here, so parity with it is unpinned (DESIGN.md section 5).
+        # Resampling is linear: wavfile_to_examples' 1/32768 (vggish_input.py:98) rides in the filter table.
+        mono = frontend.resample(frontend.as_device_mono(data), sample_rate, vggish_params.SAMPLE_RATE,
+                                 gain=1.0 / 32768.0 if _pcm16 else 1.0)
+    else:
+        mono = frontend.as_device_mono(data, pcm16=_pcm16)
+    examples = frontend.waveforms_to_examples(mono[None], out_dtype=torch.float32)
     if return_tensor:
         return examples[:, None, :, :].requires_grad_(True)
     return examples.cpu().numpy().astype(np.float64)

@@ -319,6 +319,16 @@ int mla_col_sum_bf16(const void* x, int64_t ldx, int64_t rows, int64_t cols, voi
 int mla_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, int64_t step, mla_stream_t stream);
 
+/* vggish_input.py:52-53 `resampy.resample(data, sample_rate, 16000)`: band-limited sinc interpolation (resampy/interpn.py)
+ * of a mono float32 waveform. win / delta: DEVICE tables of the interpolation filter in double precision (right half of the
+ * windowed sinc, `num_table` entries per zero crossing, already scaled by the ratio when it is < 1; delta[i] = win[i+1] - win[i],
+ * 0 for the last) -- host-side setup like the mel matrix (the package builds resampy's published 'kaiser_best' design).
+ * n_out must equal mla_resample_length() = int(n_in * sr_out / sr_in); MLA_E_SHORT if that is 0 (resampy raises ValueError).
+ * Parity with resampy itself is UNPINNED (the dependency is absent here): DESIGN.md section 5. */
+int64_t mla_resample_length(int64_t n_in, double sr_in, double sr_out);
+int mla_resample(const float* x, int64_t n_in, double sr_in, double sr_out, const double* win, const double* delta, int nwin,
+                 int num_table, float* y, int64_t n_out, mla_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Data-parallel exchange (the reference is single-process, train.py:119-142: these entry
  * points are what makes its step run sharded over the GPUs of a node) and the dropout masks of the step.

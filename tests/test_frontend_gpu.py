@@ -55,8 +55,8 @@ def test_short_inputs_behave_like_the_reference(vi, golden):
             assert tuple(t.shape) == (n_ex, 1, 96, 64)
             if n_ex:
                 assert torch.allclose(t, torch.full_like(t, float(np.log(np.float32(0.01)))), atol=1e-6)
-    with pytest.raises(NotImplementedError):
-        vi.waveform_to_examples(np.zeros(16000), 22050)
+    with pytest.raises(ValueError):
+        vi.waveform_to_examples(np.zeros(16000), 0)                # resampy: "Invalid sample rate"
 
 
 def test_batched_unaligned_int16_and_bf16(fe, W):
@@ -232,3 +232,45 @@ def test_config2_literal_shapes_against_the_oracle(fe, vi, W):
     i16 = np.round(rows * 20000).astype(np.int16)
     got16 = fe.waveforms_to_examples(torch.from_numpy(i16).cuda()).cpu().numpy()    # PCM path: 1/32768 in the kernel's read
     assert np.abs(got16 - ofe.batch_examples(i16 / 32768.0)).max() <= 1e-4
+
+
+def test_resample_branch_against_the_restated_algorithm(fe, vi, W, tmp_path):
+    """vggish_input.py:52-53 (sample_rate != 16000 -> resampy.resample(..., 'kaiser_best')). PARITY UNPINNED: resampy is not
+    installed and the reference holds no resampled fixture, so the HIP kernel is checked against oracle/resample.py, a float64
+    restatement of resampy's published algorithm and filter design (see its header) -- not against resampy itself.
+    Kernel vs restatement: <= 2e-6 absolute (float32 output of a float64 accumulation); through the log-mel: <= 1e-4."""
+    from oracle import resample as ors
+    win, num_table = fe.kaiser_best_filter()
+    w0, n0 = ors.sinc_window()
+    assert num_table == n0 == 512 and np.array_equal(win, w0) and win.shape == (64 * 512 + 1,)
+    for sr, n in ((44100, 44100 * 2 + 17), (22050, 30000), (48000, 50001), (8000, 9000), (11025, 12000), (32000, 32000)):
+        x = W.waveform(81, n, 1, dtype=np.float64)[0]
+        ref = ors.resample(x, sr, 16000)
+        got = fe.resample(torch.from_numpy(x.astype(np.float32)).cuda(), sr, 16000).cpu().numpy()
+        assert got.shape == ref.shape == (int(n * 16000 / sr),)
+        ref32 = ors.resample(x.astype(np.float32).astype(np.float64), sr, 16000)
+        assert np.abs(got - ref32).max() <= 2e-6, (sr, np.abs(got - ref32).max())
+    # a 1 kHz tone survives 44.1 -> 16 kHz; a 9 kHz tone (above the new Nyquist) is removed
+    t = np.arange(44100) / 44100.0
+    y = fe.resample(torch.from_numpy(np.sin(2 * np.pi * 1000 * t).astype(np.float32)).cuda(), 44100, 16000).cpu().numpy()
+    assert np.abs(y[300:-300] - np.sin(2 * np.pi * 1000 * np.arange(16000) / 16000.0)[300:-300]).max() < 5e-3
+    y = fe.resample(torch.from_numpy(np.sin(2 * np.pi * 9000 * t).astype(np.float32)).cuda(), 44100, 16000).cpu().numpy()
+    assert np.abs(y[500:-500]).max() < 2e-3
+    # the whole branch: stereo 44.1 kHz float waveform -> examples
+    st = W.waveform(82, 2 * 44100, 2, dtype=np.float64).T                                   # (samples, 2)
+    got = vi.waveform_to_examples(st, 44100, return_tensor=False)
+    ref = ofe.waveform_to_examples(ors.resample(st.astype(np.float32).astype(np.float64).mean(axis=1), 44100, 16000))
+    assert got.shape == ref.shape == (2, 96, 64) and np.abs(got - ref).max() <= 1e-4
+    # a 22.05 kHz 16-bit WAV file: /32768 (vggish_input.py:98) and the resampling commute
+    import wave
+    pcm = np.round(W.waveform(83, 40000, 1, dtype=np.float64)[0] * 20000).astype(np.int16)
+    path = str(tmp_path / "r.wav")
+    with wave.open(path, "wb") as wf:
+        wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(22050); wf.writeframes(pcm.tobytes())
+    got = vi.wavfile_to_examples(path, return_tensor=False)
+    ref = ofe.waveform_to_examples(ors.resample(pcm / 32768.0, 22050, 16000))
+    assert got.shape == ref.shape == (1, 96, 64) and np.abs(got - ref).max() <= 1e-4
+    with pytest.raises(ValueError):
+        fe.resample(torch.zeros(2).cuda(), 48000, 16000)          # int(2 / 3) = 0 output samples: resampy raises
+    with pytest.raises(ValueError):
+        ors.resample(np.zeros(2), 48000, 16000)

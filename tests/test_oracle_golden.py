@@ -207,3 +207,26 @@ def test_training_curve_matches_reference(golden, mk, W, tag, finetune, steps, B
     with torch.no_grad():
         ev = omodel.ensemble_forward(st.sd, mk.synth_bags(999, 4)[0], (2, 1), False)
     np.testing.assert_allclose(ev.numpy(), g[tag + "/eval_after"], rtol=0, atol=2e-2)
+
+
+def test_resample_restatement_properties():
+    """oracle/resample.py (parity unpinned: resampy is absent, see its header): structural properties of the published algorithm --
+    output length int(n * ratio), unit DC gain, a passband tone reproduced, a tone above the new Nyquist removed, exact identity
+    of the interior for ratio 1 up to the filter's rolloff ripple, ValueError where resampy raises."""
+    import pytest
+    from oracle import resample as ors
+    win, num_table = ors.sinc_window()
+    assert win.shape == (64 * 512 + 1,) and num_table == 512 and abs(win[0] - ors.ROLLOFF) < 1e-15 and abs(win[-1]) < 1e-7
+    sr = 44100
+    t = np.arange(sr) / sr
+    y = ors.resample(np.sin(2 * np.pi * 1000 * t), sr, 16000)
+    assert y.shape == (16000,)
+    assert np.abs(y[300:-300] - np.sin(2 * np.pi * 1000 * np.arange(16000) / 16000.0)[300:-300]).max() < 5e-3
+    assert np.abs(ors.resample(np.sin(2 * np.pi * 9000 * t), sr, 16000)[500:-500]).max() < 2e-3
+    assert np.abs(ors.resample(np.ones(sr), sr, 16000)[300:-300] - 1).max() < 6e-3          # DC gain (index_step truncation: 0.4 %)
+    up = ors.resample(np.sin(2 * np.pi * 1000 * np.arange(8000) / 8000.0), 8000, 16000)
+    assert up.shape == (16000,) and np.abs(up[300:-300] - np.sin(2 * np.pi * 1000 * np.arange(16000) / 16000.0)[300:-300]).max() < 1e-6
+    assert ors.resample(np.zeros(100), 16000, 8000).shape == (50,) and ors.resample(np.zeros(101), 48000, 16000).shape == (33,)
+    for bad in ((np.zeros(2), 48000, 16000), (np.zeros(10), 0, 16000), (np.zeros(10), 16000, -1)):
+        with pytest.raises(ValueError):
+            ors.resample(*bad)
