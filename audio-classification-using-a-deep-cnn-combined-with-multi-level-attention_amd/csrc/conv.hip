@@ -22,6 +22,8 @@
 //   W >= 16 : an m-subtile = 16 consecutive x of one image row; rows y / y+1 are the wave's
 //             subtiles i / i+1, x pairs are accumulator registers (0,1) / (2,3);
 //   W == 8  : an m-subtile = 8 x of image a + 8 x of image a+1 (same row).
+#include <type_traits>
+
 #include "common.h"
 #include "mma_core.h"
 
@@ -30,6 +32,26 @@ namespace {
 using namespace mma;
 
 constexpr int kThreads = 512, kWavesN = 4, kMS = 6;
+
+// Diagnostic build only (-DMLA_CONV_STAMPS=1, scripts/build_variant.py): s_memtime stamps of ONE tap (tap 4 of a workgroup's
+// second channel chunk) of waves 0 and 4 of the first 8 workgroups, written to a buffer nothing else reads; read back through
+// mla_debug_conv_stamps(). The shipped kernel executes no stamp.
+#ifndef MLA_CONV_STAMPS
+#define MLA_CONV_STAMPS 0
+#endif
+#if MLA_CONV_STAMPS
+__device__ unsigned long long g_conv_stamps[8][2][8];
+#define MLA_STAMP(k) do { if (stamp_on) stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MLA_STAMP(k) do { } while (0)
+#endif
+
+#ifndef MLA_CONV_PRIO
+#define MLA_CONV_PRIO 1             // 1: waves 4-7 run at s_setprio 1 (shipped: +1.2 ... 1.9 % with the stagger), 2: waves 0-3 do, 0: nobody
+#endif
+#ifndef MLA_CONV_STAGGER
+#define MLA_CONV_STAGGER 1          // 0: A/B builds without the half-tap stagger of waves 4-7 (scripts/build_variant.py)
+#endif
 
 // SPLIT ("bf16x3"): every f32 value x travels as two bf16, hi = bf16(x) and lo = bf16(x - hi) (x = hi + lo to 2^-18
 // relative). Activations hold [hi(C) | lo(C)] per pixel, repacked weights [hi | lo | hi] per 64-channel chunk and tap, and
@@ -63,6 +85,12 @@ struct Cfg {
     static constexpr bool A_DMA = PERSIST;                  // input patches by LDS-DMA into two alternating buffers (else: one
                                                             // buffer, register-staged -- the two-workgroups-per-CU configurations)
     static constexpr int A_BUFS = A_DMA ? 2 : 1;
+    // Stagger (one workgroup per CU = two waves per SIMD that would otherwise run in lockstep): waves 4-7 -- the SIMD partners
+    // of waves 0-3 -- run half a tap behind. Their k-step-1 fragments are READ before the barrier that ends a tap (the slice is
+    // still valid there) and MULTIPLIED after it, so right after every barrier one wave of each SIMD has a full burst of MFMAs
+    // ready while its partner waits for the fragments of the next tap: the matrix pipe no longer idles behind each barrier.
+    // Every accumulator still receives its products in the same order: results are bit-identical.
+    static constexpr bool STAGGER = PERSIST && MLA_CONV_STAGGER;
     static constexpr int LDS_BYTES = A_BUFS * A_BYTES + 2 * B_BYTES;
     static constexpr int HO = POOL ? H / 2 : H, WO = POOL ? W / 2 : W;
     static_assert(W == 32 || W == 16 || W == 8, "tile mapping covers the VGGish widths");
@@ -260,6 +288,20 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
     // into the other patch buffer early in the current chunk (register-staged and swapped in behind one extra barrier
     // where only one patch buffer fits), so no global round trip is exposed at a boundary.
     int par = 0;                                   // parity of the running tap counter -> current weight buffer
+    const bool late = C::STAGGER && __builtin_amdgcn_readfirstlane(wave) >= 4;
+#if MLA_CONV_PRIO == 1
+    if (C::PERSIST && __builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);
+#elif MLA_CONV_PRIO == 2
+    if (C::PERSIST && __builtin_amdgcn_readfirstlane(wave) < 4) __builtin_amdgcn_s_setprio(1);
+#endif
+    // two copies of the tile loop, selected once per wave (a scalar branch): LATE = the staggered schedule of waves 4-7
+#if MLA_CONV_STAMPS
+    unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int chunk_counter = 0;
+#endif
+    auto run = [&](auto late_c) {
+    constexpr bool LATE = decltype(late_c)::value;
+    u32x4 af[kMS], bf[C::NS];                      // fragments of one k-step (late waves carry them across the barrier)
     for (;;) {
         const int next_tile = tile + int(gridDim.x);
         const bool has_next = C::PERSIST && next_tile < n_tiles;
@@ -285,26 +327,59 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                         a_load(last_chunk ? 0 : a_chan(c + 1));
                     }
                 }
-                _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {
-                    u32x4 af[kMS], bf[C::NS];
+                auto rd = [&](int ks) {
                     _Pragma("unroll") for (int i = 0; i < kMS; ++i)
                         af[i] = lds_read16(sA + abuf * C::A_BYTES, (abase[kx] ^ (ks << 6)) + (i + ky) * C::PW * kRowBytes);
                     _Pragma("unroll") for (int j = 0; j < C::NS; ++j)
                         bf[j] = lds_read16(sB, cur + (bbase ^ (ks << 6)) + j * 16 * kRowBytes);
-                    // Coarse phases: every fragment read of the k-step is issued before the first MFMA and
-                    // the MFMAs run as one burst. Left alone, hipcc re-reads two A fragments at a time with a
-                    // short LDS wait in front of every 8 MFMAs; the two waves of a SIMD then wait and compute
-                    // in lockstep (SQ_WAIT_ANY 49 %, MFMA pipe 51 % busy at the held clock).
+                };
+                // Coarse phases: every fragment read of the k-step is issued before the first MFMA and
+                // the MFMAs run as one burst. Left alone, hipcc re-reads two A fragments at a time with a
+                // short LDS wait in front of every 8 MFMAs; the two waves of a SIMD then wait and compute
+                // in lockstep (SQ_WAIT_ANY 49 %, MFMA pipe 51 % busy at the held clock).
+                auto mm = [&]() {
                     __builtin_amdgcn_sched_barrier(0);
                     _Pragma("unroll") for (int i = 0; i < kMS; ++i)
                         _Pragma("unroll") for (int j = 0; j < C::NS; ++j) mma_step<T>(af[i], bf[j], acc[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
+                };
+#if MLA_CONV_STAMPS
+                const bool stamp_on = tap == 4 && chunk_counter == 5 && (wave == 0 || wave == 4) && blockIdx.x < 8 && blockIdx.y == 0;
+#endif
+                if constexpr (!LATE) {
+                    MLA_STAMP(0);
+                    rd(0);
+                    MLA_STAMP(1);
+#if MLA_CONV_STAMPS
+                    if (stamp_on) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                    MLA_STAMP(2);
+                    mm();
+                    MLA_STAMP(3);
+                    rd(1);
+#if MLA_CONV_STAMPS
+                    if (stamp_on) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                    MLA_STAMP(4);
+                    mm();
+                    MLA_STAMP(5);
+                } else {
+                    if (tap > 0 || c > 0) mm();    // k-step 1 of the previous tap: fragments were read before the barrier
+                    rd(0); mm();
+                    rd(1);                         // multiplied after the barrier
+                    // the reads must have left the slice before the barrier lets the next DMA overwrite it
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
                 // The DMA'd slice must have landed before the barrier that publishes it: LDS-DMA is ordered for a ds_read only
                 // by the issuing wave's vmcnt followed by a barrier. hipcc emits this wait itself in front of
                 // __syncthreads() while a DMA is in flight; it is spelled out so correctness does not rest on that.
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                MLA_STAMP(6);
                 __syncthreads();                   // ... and every wave is done with `cur`
+                MLA_STAMP(7);
+#if MLA_CONV_STAMPS
+                if (tap == 8) ++chunk_counter;
+#endif
                 if constexpr (C::A_DMA) {
                     if (tap == 8 && new_patch) abuf ^= 1;
                 } else {
@@ -317,6 +392,12 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
             }
         }
 
+        if constexpr (LATE) {                      // the last tap's second k-step
+            __builtin_amdgcn_sched_barrier(0);
+            _Pragma("unroll") for (int i = 0; i < kMS; ++i)
+                _Pragma("unroll") for (int j = 0; j < C::NS; ++j) mma_step<T>(af[i], bf[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // epilogue: ReLU (+ lane-local 2x2 max-pool; max commutes with the monotone ReLU; the bias is already in the
         // accumulators); one vector store per pixel.
         {
@@ -357,6 +438,17 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
         _Pragma("unroll") for (int i = 0; i < kMS; ++i)
             _Pragma("unroll") for (int j = 0; j < C::NS; ++j) acc[i][j] = f32x4{bv[j], bv[j], bv[j], bv[j]};
     }
+    };
+    if constexpr (C::STAGGER) {
+        if (late) run(std::true_type{});
+        else run(std::false_type{});
+    } else {
+        run(std::false_type{});
+    }
+#if MLA_CONV_STAMPS
+    if ((wave == 0 || wave == 4) && lane == 0 && blockIdx.x < 8 && blockIdx.y == 0)
+        for (int k = 0; k < 8; ++k) g_conv_stamps[blockIdx.x][wave >> 2][k] = stamps[k];
+#endif
 }
 
 // ---------------------------------------------------------------- conv1 (Cin = 1) ----------
@@ -604,6 +696,12 @@ int conv_generic(const void* in, const void* w, const float* bias, void* out, in
 }
 
 }  // namespace
+
+#if MLA_CONV_STAMPS
+extern "C" int mla_debug_conv_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_conv_stamps), sizeof(g_conv_stamps)) == hipSuccess ? 0 : -4;
+}
+#endif
 
 extern "C" int mla_conv3x3(const void* in, const void* w_packed, const float* bias, void* out, int64_t n, int H, int W,
                            int cin, int cout, int pool, int act, int dtype, mla_stream_t stream) {

@@ -8,6 +8,8 @@
 // 128 x (64 NS), 128-byte K chunks (64 bf16 / 32 f32) double-buffered in LDS with the next
 // chunk's global loads in flight behind the MFMAs; M / N / K tails are zero-filled on load and
 // masked on store. bf16 uses v_mfma_f32_16x16x32_bf16, f32 the exact v_mfma_f32_16x16x4_f32.
+#include <type_traits>
+
 #include "common.h"
 #include "mma_core.h"
 
@@ -16,6 +18,10 @@ namespace {
 using namespace mma;
 
 constexpr int kThreads = 512;
+
+#ifndef MLA_GEMM_STAGGER
+#define MLA_GEMM_STAGGER 1          // 0: A/B builds without the half-stage stagger of waves 4-7 (scripts/build_variant.py)
+#endif
 
 // DMA: both operand tiles go global -> LDS by LDS-DMA (buffer_load ... lds, 1 KiB = 8 tile rows per wave-instruction, the
 // tile's XOR swizzle applied on the source side) instead of through registers + ds_write: no staging registers, no
@@ -119,26 +125,60 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
         lwrite(s_begin & 1);
     }
     __syncthreads();
-    for (int s = s_begin; s < stages; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < stages) {
-            if (DMA) dma(s + 1, buf ^ 1);      // the other buffer's last readers passed the barrier that ended stage s - 1
-            else gload(s + 1);
+    // Stagger (DMA path: one workgroup per CU): waves 4-7, the SIMD partners of waves 0-3, run half a stage behind -- their
+    // k-step-1 fragments are read before the barrier that ends a stage and multiplied after it -- and at s_setprio 1; see
+    // conv.hip (Cfg::STAGGER). Same products in the same order per accumulator: bit-identical results.
+    constexpr bool STAGGER = DMA && MLA_GEMM_STAGGER;
+    const bool late = STAGGER && __builtin_amdgcn_readfirstlane(wave) >= 4;
+    if (STAGGER && late) __builtin_amdgcn_s_setprio(1);
+    auto run = [&](auto late_c) {
+        constexpr bool LATE = decltype(late_c)::value;
+        u32x4 af[kMS], bf[NS];
+        for (int s = s_begin; s < stages; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < stages) {
+                if (DMA) dma(s + 1, buf ^ 1);      // the other buffer's last readers passed the barrier that ended stage s - 1
+                else gload(s + 1);
+            }
+            auto rd = [&](int ks) {
+                _Pragma("unroll") for (int i = 0; i < kMS; ++i)
+                    af[i] = lds_read16(sA, buf * A_BYTES + (abase ^ (ks << 6)) + i * 16 * kRowBytes);
+                _Pragma("unroll") for (int j = 0; j < NS; ++j)
+                    bf[j] = lds_read16(sB, buf * B_BYTES + (bbase ^ (ks << 6)) + j * 16 * kRowBytes);
+            };
+            auto mm = [&]() {                      // coarse phases: all reads, then one MFMA burst (see conv.hip)
+                __builtin_amdgcn_sched_barrier(0);
+                _Pragma("unroll") for (int i = 0; i < kMS; ++i)
+                    _Pragma("unroll") for (int j = 0; j < NS; ++j) mma_step<T>(af[i], bf[j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if constexpr (!LATE) {
+                rd(0); mm();
+                rd(1); mm();
+            } else {
+                if (s > s_begin) mm();             // k-step 1 of the previous stage
+                rd(0); mm();
+                rd(1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the reads have left the buffer before the next DMA may land in it
+            }
+            if (!DMA && s + 1 < stages) lwrite(buf ^ 1);   // the other buffer was last read before the previous barrier
+            if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {
-            u32x4 af[kMS], bf[NS];
-            _Pragma("unroll") for (int i = 0; i < kMS; ++i)
-                af[i] = lds_read16(sA, buf * A_BYTES + (abase ^ (ks << 6)) + i * 16 * kRowBytes);
-            _Pragma("unroll") for (int j = 0; j < NS; ++j)
-                bf[j] = lds_read16(sB, buf * B_BYTES + (bbase ^ (ks << 6)) + j * 16 * kRowBytes);
-            __builtin_amdgcn_sched_barrier(0);     // coarse phases: all reads, then one MFMA burst (see conv.hip)
-            _Pragma("unroll") for (int i = 0; i < kMS; ++i)
-                _Pragma("unroll") for (int j = 0; j < NS; ++j) mma_step<T>(af[i], bf[j], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LATE) {
+            if (stages > s_begin) {
+                __builtin_amdgcn_sched_barrier(0);
+                _Pragma("unroll") for (int i = 0; i < kMS; ++i)
+                    _Pragma("unroll") for (int j = 0; j < NS; ++j) mma_step<T>(af[i], bf[j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (!DMA && s + 1 < stages) lwrite(buf ^ 1);   // the other buffer was last read before the previous barrier
-        if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    };
+    if constexpr (STAGGER) {
+        if (late) run(std::true_type{});
+        else run(std::false_type{});
+    } else {
+        run(std::false_type{});
     }
 
     if (partial) {                          // raw sums of this K range; bias / activation happen in the reduction
