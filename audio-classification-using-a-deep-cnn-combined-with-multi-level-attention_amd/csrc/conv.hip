@@ -47,7 +47,10 @@ __device__ unsigned long long g_conv_stamps[8][2][8];
 #endif
 
 #ifndef MLA_CONV_PRIO
-#define MLA_CONV_PRIO 1             // 1: waves 4-7 run at s_setprio 1 (shipped: +1.2 ... 1.9 % with the stagger), 2: waves 0-3 do, 0: nobody
+#define MLA_CONV_PRIO 3             // 3 (shipped): burst priorities 3 / 2 / 1 / 0 so that no MFMA burst is preempted; 1: waves 4-7 static prio 1; 0: none
+#endif
+#ifndef MLA_CONV_DMA_LATE
+#define MLA_CONV_DMA_LATE 1
 #endif
 #ifndef MLA_CONV_STAGGER
 #define MLA_CONV_STAGGER 1          // 0: A/B builds without the half-tap stagger of waves 4-7 (scripts/build_variant.py)
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
     // where only one patch buffer fits), so no global round trip is exposed at a boundary.
     int par = 0;                                   // parity of the running tap counter -> current weight buffer
     const bool late = C::STAGGER && __builtin_amdgcn_readfirstlane(wave) >= 4;
-#if MLA_CONV_PRIO == 1
+#if MLA_CONV_PRIO == 1 || MLA_CONV_PRIO == 3
     if (C::PERSIST && __builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);
 #elif MLA_CONV_PRIO == 2
     if (C::PERSIST && __builtin_amdgcn_readfirstlane(wave) < 4) __builtin_amdgcn_s_setprio(1);
@@ -313,20 +316,25 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
             _Pragma("unroll") for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap % 3;
                 const int cur = par ? C::B_BYTES : 0;
-                // next weight slice into the other buffer (its last readers passed the barrier that ended the previous tap)
-                if (tap < 8) b_dma(c0, tap + 1, cur ^ C::B_BYTES);
-                else if (more) b_dma(last_chunk ? 0 : c0 + C::KC, 0, cur ^ C::B_BYTES);
-                if constexpr (C::A_DMA) {
-                    if (tap == 2 && new_patch) {   // next chunk's / tile's patch into the other patch buffer (idle since the previous chunk)
-                        if (last_chunk) a_rsrc = patch_rsrc((next_tile / C::TILES_Y) * C::IMGS);
-                        a_dma(last_chunk ? 0 : a_chan(c + 1), abuf ^ 1);
+                // next weight slice into the other buffer (its last readers passed the barrier that ended the previous tap) and, once
+                // per chunk, the next patch. Issued AFTER the wave's first fragment reads (MLA_CONV_DMA_LATE): a DMA piece costs the
+                // issuing wave 60-185 cycles, the data is not needed before the end of the tap, and the partner of a wave that
+                // reads first gets the matrix pipe ~300 cycles earlier (in-kernel stamps: profiles/r02_conv_stamps.txt)
+                auto issue_dma = [&]() {
+                    if (tap < 8) b_dma(c0, tap + 1, cur ^ C::B_BYTES);
+                    else if (more) b_dma(last_chunk ? 0 : c0 + C::KC, 0, cur ^ C::B_BYTES);
+                    if constexpr (C::A_DMA) {
+                        if (tap == 2 && new_patch) {   // next chunk's / tile's patch into the other patch buffer (idle since the previous chunk)
+                            if (last_chunk) a_rsrc = patch_rsrc((next_tile / C::TILES_Y) * C::IMGS);
+                            a_dma(last_chunk ? 0 : a_chan(c + 1), abuf ^ 1);
+                        }
+                    } else {
+                        if (tap == 5 && new_patch) {
+                            if (last_chunk) a_rsrc = patch_rsrc((next_tile / C::TILES_Y) * C::IMGS);
+                            a_load(last_chunk ? 0 : a_chan(c + 1));
+                        }
                     }
-                } else {
-                    if (tap == 5 && new_patch) {
-                        if (last_chunk) a_rsrc = patch_rsrc((next_tile / C::TILES_Y) * C::IMGS);
-                        a_load(last_chunk ? 0 : a_chan(c + 1));
-                    }
-                }
+                };
                 auto rd = [&](int ks) {
                     _Pragma("unroll") for (int i = 0; i < kMS; ++i)
                         af[i] = lds_read16(sA + abuf * C::A_BYTES, (abase[kx] ^ (ks << 6)) + (i + ky) * C::PW * kRowBytes);
@@ -348,7 +356,12 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
 #endif
                 if constexpr (!LATE) {
                     MLA_STAMP(0);
+#if MLA_CONV_PRIO == 3
+                    __builtin_amdgcn_s_setprio(2);             // its first burst outranks the partner's k-step-0 burst (prio 1)
+#endif
+                    if (!MLA_CONV_DMA_LATE) issue_dma();
                     rd(0);
+                    if (MLA_CONV_DMA_LATE) issue_dma();
                     MLA_STAMP(1);
 #if MLA_CONV_STAMPS
                     if (stamp_on) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -356,6 +369,9 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                     MLA_STAMP(2);
                     mm();
                     MLA_STAMP(3);
+#if MLA_CONV_PRIO == 3
+                    __builtin_amdgcn_s_setprio(0);             // ... its second burst yields to it
+#endif
                     rd(1);
 #if MLA_CONV_STAMPS
                     if (stamp_on) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -364,11 +380,29 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                     mm();
                     MLA_STAMP(5);
                 } else {
+#if MLA_CONV_PRIO == 3
+                    __builtin_amdgcn_s_setprio(3);             // the carried-over burst goes first, uninterrupted
+#endif
+                    MLA_STAMP(0);
+                    if (!MLA_CONV_DMA_LATE) issue_dma();
                     if (tap > 0 || c > 0) mm();    // k-step 1 of the previous tap: fragments were read before the barrier
-                    rd(0); mm();
+                    if (MLA_CONV_DMA_LATE) issue_dma();
+                    MLA_STAMP(1);
+#if MLA_CONV_PRIO == 3
+                    __builtin_amdgcn_s_setprio(1);
+#endif
+                    rd(0);
+#if MLA_CONV_STAMPS
+                    if (stamp_on) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                    MLA_STAMP(2);
+                    mm();
+                    MLA_STAMP(3);
                     rd(1);                         // multiplied after the barrier
+                    MLA_STAMP(4);
                     // the reads must have left the slice before the barrier lets the next DMA overwrite it
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    MLA_STAMP(5);
                 }
                 // The DMA'd slice must have landed before the barrier that publishes it: LDS-DMA is ordered for a ds_read only
                 // by the issuing wave's vmcnt followed by a barrier. hipcc emits this wait itself in front of

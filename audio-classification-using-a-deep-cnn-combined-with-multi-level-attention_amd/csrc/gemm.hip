@@ -19,6 +19,9 @@ using namespace mma;
 
 constexpr int kThreads = 512;
 
+#ifndef MLA_GEMM_PRIO
+#define MLA_GEMM_PRIO 3             // 3: burst priorities (see conv.hip), 1: waves 4-7 static s_setprio 1
+#endif
 #ifndef MLA_GEMM_STAGGER
 #define MLA_GEMM_STAGGER 1          // 0: A/B builds without the half-stage stagger of waves 4-7 (scripts/build_variant.py)
 #endif
@@ -136,10 +139,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
         u32x4 af[kMS], bf[NS];
         for (int s = s_begin; s < stages; ++s) {
             const int buf = s & 1;
-            if (s + 1 < stages) {
-                if (DMA) dma(s + 1, buf ^ 1);      // the other buffer's last readers passed the barrier that ended stage s - 1
-                else gload(s + 1);
-            }
+            auto stage_next = [&]() {              // next stage's operands; issued after the wave's first reads / carried-over burst
+                if (s + 1 < stages) {
+                    if (DMA) dma(s + 1, buf ^ 1);  // the other buffer's last readers passed the barrier that ended stage s - 1
+                    else gload(s + 1);
+                }
+            };
             auto rd = [&](int ks) {
                 _Pragma("unroll") for (int i = 0; i < kMS; ++i)
                     af[i] = lds_read16(sA, buf * A_BYTES + (abase ^ (ks << 6)) + i * 16 * kRowBytes);
@@ -152,11 +157,20 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
                     _Pragma("unroll") for (int j = 0; j < NS; ++j) mma_step<T>(af[i], bf[j], acc[i][j]);
                 __builtin_amdgcn_sched_barrier(0);
             };
+            // burst priorities (conv.hip, MLA_CONV_PRIO 3): carried-over burst 3 > early k-step 0 2 > late k-step 0 1 > early k-step 1 0,
+            // so that no MFMA burst is preempted by the SIMD partner and the bursts alternate late, early, late, early
             if constexpr (!LATE) {
-                rd(0); mm();
+                if (STAGGER && MLA_GEMM_PRIO == 3) __builtin_amdgcn_s_setprio(2);
+                rd(0);
+                stage_next();
+                mm();
+                if (STAGGER && MLA_GEMM_PRIO == 3) __builtin_amdgcn_s_setprio(0);
                 rd(1); mm();
             } else {
+                if (MLA_GEMM_PRIO == 3) __builtin_amdgcn_s_setprio(3);
                 if (s > s_begin) mm();             // k-step 1 of the previous stage
+                stage_next();
+                if (MLA_GEMM_PRIO == 3) __builtin_amdgcn_s_setprio(1);
                 rd(0); mm();
                 rd(1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the reads have left the buffer before the next DMA may land in it

@@ -18,10 +18,11 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * (8 * 2 * 8))()
 assert L.lib().mla_debug_conv_stamps(buf) == 0
 names = ["rd0 issue", "rd0 wait", "mm0", "rd1 issue+wait", "mm1", "to vmcnt(0)", "barrier"]
+late_names = ["mm(prev ks1)", "rd0 issue+wait", "mm0", "rd1 issue", "rd1 wait", "to vmcnt(0)", "barrier"]
 for blk in range(8):
     for wv in range(2):
         s = [buf[(blk * 2 + wv) * 8 + k] for k in range(8)]
         if s[0] == 0:
             continue
         d = [s[k + 1] - s[k] for k in range(7)]
-        print("wg %d wave %d: " % (blk, wv * 4) + ", ".join("%s %d" % (nm, v) for nm, v in zip(names, d)) + " | tap total %d (t0 %d)" % (s[7] - s[0], s[0] % 100000))
+        print("wg %d wave %d: " % (blk, wv * 4) + ", ".join("%s %d" % (nm, v) for nm, v in zip(late_names if (wv and os.environ.get("STAGGERED")) else names, d)) + " | tap total %d (t0 %d)" % (s[7] - s[0], s[0] % 100000))
