@@ -49,6 +49,9 @@ __device__ unsigned long long g_conv_stamps[8][2][8];
 #ifndef MLA_CONV_PRIO
 #define MLA_CONV_PRIO 3             // 3 (shipped): burst priorities 3 / 2 / 1 / 0 so that no MFMA burst is preempted; 1: waves 4-7 static prio 1; 0: none
 #endif
+#ifndef MLA_CONV_NARROW_PERSIST
+#define MLA_CONV_NARROW_PERSIST 0   // 1: conv2's bf16 inference configuration as one persistent workgroup per CU (A/B builds)
+#endif
 #ifndef MLA_CONV_DMA_LATE
 #define MLA_CONV_DMA_LATE 1
 #endif
@@ -82,7 +85,7 @@ struct Cfg {
     static constexpr int A_BYTES = (A_PIX + 7) / 8 * 8 * kRowBytes;   // padded to whole 1 KiB LDS-DMA pieces
     static constexpr int B_BYTES = BN * kRowBytes;
     static constexpr int TILES_Y = H / TH;
-    static constexpr bool PERSIST = NS > 2 || SPLIT;        // conv2 (half-width tile): two non-persistent workgroups per CU
+    static constexpr bool PERSIST = NS > 2 || SPLIT || (MLA_CONV_NARROW_PERSIST && sizeof(T) == 2 && NS == 2 && POOL_ && ACT_);        // conv2 (half-width tile): two non-persistent workgroups per CU
                                                             // (its split form has a 3x longer K loop and more epilogue registers)
     static constexpr int MIN_WAVES = (PERSIST || sizeof(T) == 4) ? 2 : 4;      // waves per SIMD the register budget is held to
     static constexpr bool A_DMA = PERSIST;                  // input patches by LDS-DMA into two alternating buffers (else: one

@@ -385,6 +385,9 @@ def main():
     ap.add_argument("--no-train-leg", action="store_true", help="skip the config-4 training-step leg of the N = 1 line")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse N>1 on one GPU)")
     ap.add_argument("--launch-timeout", type=int, default=1500, help="seconds the self-launched ranks may run")
+    ap.add_argument("--prewarm-seconds", type=float, default=1.5,
+                    help="device warm-up before the W warm-up steps: the first seconds of work on an idle MI355X run at ramping clocks "
+                         "(measured: the first process on a fresh box is 8-10 %% slower); untimed, like model construction")
     ap.add_argument("--dry-run", action="store_true", help="launch-path self-test: no GPU work (CPU tests)")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -442,6 +445,10 @@ def infer_mode(args, world, rank, device, ops):
         torch.cuda.synchronize()
 
     with torch.no_grad():
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < args.prewarm_seconds:     # clocks up before anything is measured (not part of W or K)
+            ens.forward_waveforms(pcm)
+            torch.cuda.synchronize()
         for _ in range(args.warmup):
             out = ens.forward_waveforms(pcm)
         assert tuple(out.shape) == (args.bags, 10) and bool(torch.isfinite(out).all())

@@ -1,5 +1,5 @@
 """Training-step benchmark (BASELINE config 4: 512 bags = 5 120 clips of 96x64 log-mel per step, Adam):
-frozen-CNN (reference default) in bf16 and f32 CNN precision, and finetune (f32)."""
+frozen-CNN (reference default) in bf16 and f32 CNN precision, and finetune in bf16 (f32 master weights) and in exact f32."""
 import importlib, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -34,4 +34,5 @@ if __name__ == "__main__":
     bags = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     print(json.dumps(run(bags, False, "bf16")))
     print(json.dumps(run(bags, False, "f32")))
+    print(json.dumps(run(bags, True, "bf16")))
     print(json.dumps(run(bags, True, "f32", steps=3)))
