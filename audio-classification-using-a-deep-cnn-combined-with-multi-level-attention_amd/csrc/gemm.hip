@@ -19,6 +19,16 @@ using namespace mma;
 
 constexpr int kThreads = 512;
 
+// Diagnostic build only (-DMLA_GEMM_STAMPS=1): s_memtime stamps of stage 100 of waves 0 and 4 of the first 8 workgroups (see conv.hip)
+#ifndef MLA_GEMM_STAMPS
+#define MLA_GEMM_STAMPS 0
+#endif
+#if MLA_GEMM_STAMPS
+__device__ unsigned long long g_gemm_stamps[8][2][8];
+#define MLA_GSTAMP(k) do { if (stamp_on) stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MLA_GSTAMP(k) do { } while (0)
+#endif
 #ifndef MLA_GEMM_PRIO
 #define MLA_GEMM_PRIO 3             // 3: burst priorities (see conv.hip), 1: waves 4-7 static s_setprio 1
 #endif
@@ -134,11 +144,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
     constexpr bool STAGGER = DMA && MLA_GEMM_STAGGER;
     const bool late = STAGGER && __builtin_amdgcn_readfirstlane(wave) >= 4;
     if (STAGGER && late) __builtin_amdgcn_s_setprio(1);
+#if MLA_GEMM_STAMPS
+    unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     auto run = [&](auto late_c) {
         constexpr bool LATE = decltype(late_c)::value;
         u32x4 af[kMS], bf[NS];
         for (int s = s_begin; s < stages; ++s) {
             const int buf = s & 1;
+#if MLA_GEMM_STAMPS
+            const bool stamp_on = s == 100 && (wave == 0 || wave == 4) && blockIdx.x < 8 && blockIdx.y == 0 && kMS == 8;
+#endif
             auto stage_next = [&]() {              // next stage's operands; issued after the wave's first reads / carried-over burst
                 if (s + 1 < stages) {
                     if (DMA) dma(s + 1, buf ^ 1);  // the other buffer's last readers passed the barrier that ended stage s - 1
@@ -161,23 +177,38 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
             // so that no MFMA burst is preempted by the SIMD partner and the bursts alternate late, early, late, early
             if constexpr (!LATE) {
                 if (STAGGER && MLA_GEMM_PRIO == 3) __builtin_amdgcn_s_setprio(2);
+                MLA_GSTAMP(0);
                 rd(0);
+                MLA_GSTAMP(1);
                 stage_next();
+                MLA_GSTAMP(2);
                 mm();
+                MLA_GSTAMP(3);
                 if (STAGGER && MLA_GEMM_PRIO == 3) __builtin_amdgcn_s_setprio(0);
-                rd(1); mm();
+                rd(1);
+                MLA_GSTAMP(4);
+                mm();
+                MLA_GSTAMP(5);
             } else {
                 if (MLA_GEMM_PRIO == 3) __builtin_amdgcn_s_setprio(3);
+                MLA_GSTAMP(0);
                 if (s > s_begin) mm();             // k-step 1 of the previous stage
+                MLA_GSTAMP(1);
                 stage_next();
+                MLA_GSTAMP(2);
                 if (MLA_GEMM_PRIO == 3) __builtin_amdgcn_s_setprio(1);
                 rd(0); mm();
+                MLA_GSTAMP(3);
                 rd(1);
+                MLA_GSTAMP(4);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the reads have left the buffer before the next DMA may land in it
+                MLA_GSTAMP(5);
             }
             if (!DMA && s + 1 < stages) lwrite(buf ^ 1);   // the other buffer was last read before the previous barrier
             if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MLA_GSTAMP(6);
             __syncthreads();
+            MLA_GSTAMP(7);
         }
         if constexpr (LATE) {
             if (stages > s_begin) {
@@ -195,6 +226,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
         run(std::false_type{});
     }
 
+#if MLA_GEMM_STAMPS
+    if ((wave == 0 || wave == 4) && lane == 0 && blockIdx.x < 8 && blockIdx.y == 0 && kMS == 8 && stages > 100)
+        for (int k = 0; k < 8; ++k) g_gemm_stamps[blockIdx.x][wave >> 2][k] = stamps[k];
+#endif
     if (partial) {                          // raw sums of this K range; bias / activation happen in the reduction
         float* pout = partial + size_t(blockIdx.z) * M * N;
         _Pragma("unroll") for (int j = 0; j < NS; ++j) {
@@ -312,6 +347,12 @@ int dispatch(const void* a, int64_t lda, const void* w, int64_t ldw, const float
 }
 
 }  // namespace
+
+#if MLA_GEMM_STAMPS
+extern "C" int mla_debug_gemm_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_stamps), sizeof(g_gemm_stamps)) == hipSuccess ? 0 : -4;
+}
+#endif
 
 // Split-K form for reductions over a long K with few output tiles (weight gradients dW = dZ^T . X:
 // M, N = layer widths, K = batch rows): `splits` K ranges accumulate into workspace[splits][M][N]
