@@ -38,6 +38,10 @@ def lib():
             raise RuntimeError(
                 "%s is missing: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
                 "There is no fallback path." % LIB_PATH)
+        # PyTorch ships its own HIP runtime (torch/lib/libamdhip64.so); libmla_hip.so is linked against the same SONAME. torch must
+        # be in the process FIRST so that both use one runtime: loaded the other way round the system runtime comes in with this
+        # library, torch brings its own, and the second one finds no device ("no ROCm-capable device is detected").
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         L.mla_last_error.restype = ctypes.c_char_p
         L.mla_logmel_table_floats.restype = ctypes.c_int64
