@@ -66,6 +66,7 @@ def lib():
         L.mla_vggish_conv.argtypes = [ci, vp, vp, vp, vp, i64, ci, vp]
         L.mla_linear.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, ci, ci, ci, vp]
         L.mla_linear_small.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, vp]
+        L.mla_linear_narrow.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, vp]
         L.mla_linear_splitk.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, ci, ci, vp, i64, vp]
         L.mla_bn_stats_workspace_bytes.restype = i64
         L.mla_bn_stats.argtypes = [vp, i64, i64, i64, ci, ci, vp, vp, vp, vp, vp, cf, vp]

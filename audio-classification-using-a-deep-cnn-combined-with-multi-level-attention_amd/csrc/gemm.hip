@@ -342,6 +342,16 @@ int dispatch(const void* a, int64_t lda, const void* w, int64_t ldw, const float
     }
     if (wide) return relu ? launch<T, TO, 4, 4, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit)
                           : launch<T, TO, 4, 4, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit);
+    // narrow layers (N <= 128: the embeddings' last Linear 4096 -> 128, the head's 128 -> 600 tail tiles) at batch sizes where
+    // 128-row tiles leave most CUs idle: 64-row tiles double the workgroups (the K loop per output element is unchanged, so the
+    // bits are too)
+    {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (((M + 127) / 128) * ((N + 127) / 128) < cus && M > 64)
+            return relu ? launch<T, TO, 2, 2, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit)
+                        : launch<T, TO, 2, 2, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit);
+    }
     return relu ? launch<T, TO, 4, 2, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit)
                 : launch<T, TO, 4, 2, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit);
 }

@@ -56,8 +56,8 @@ def attention_forward(am, h, y, ctx=None, level=0):
     z = ops.linear(rows, am.fcv.weight.detach(), am.fcv.bias.detach())
     if am.training:
         # both norms see the same z, hence the same batch statistics; each keeps its own buffers
-        mean, var = ops.bn_stats_sync(z, 0, T, ctx.dist, am.normv.running_mean, am.normv.running_var, am.normv.momentum)
-        ops.bn_stats_sync(z, 0, T, ctx.dist, am.normf.running_mean, am.normf.running_var, am.normf.momentum)
+        mean, var = ops.bn_stats_sync(z, 0, T, ctx.dist, am.normv.running_mean, am.normv.running_var, am.normv.momentum,
+                                      also=((am.normf.running_mean, am.normf.running_var, am.normf.momentum),))
         am.normv.num_batches_tracked += 1
         am.normf.num_batches_tracked += 1
         nv = (mean, var, am.normv.weight.detach(), am.normv.bias.detach())

@@ -144,6 +144,12 @@ def linear(a, w, b, relu=False, out_dtype=None, out=None, split_k=False):
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
     else:
         assert out.is_contiguous() and out.numel() == M * N and out.dtype == out_dtype
+    # narrow outputs (the attention modules' 600 -> 10 fcv): a dedicated one-pass kernel instead of a nearly empty MFMA tile
+    if (N <= 16 and a.dtype == torch.float32 and out_dtype == torch.float32 and not relu and not split_k and K % 4 == 0
+            and K * N * 4 <= 65536 and a.stride(0) % 4 == 0 and w.stride(0) % 4 == 0):
+        _lib.check(_timed("linear_%dx%d" % (K, N), _lib.lib().mla_linear_narrow, _p(a), a.stride(0), _p(w), w.stride(0), _p(b), _p(out), N,
+                          M, N, K, _lib.stream_ptr()))
+        return out
     # few output tiles but a long reduction (weight gradients): split K over workgroups
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if split_k and a.dtype == torch.float32 and out_dtype == torch.float32 and tiles <= 64 and K >= 2048:
@@ -313,8 +319,10 @@ def dropout_mask(n, seed, stream_id, offset, p_drop, device):
     return out
 
 
-def bn_stats_sync(x, mode, period, dist, running_mean=None, running_var=None, momentum=-1.0):
-    """bn_stats with the (sum, sum of squares) all-reduced over the data-parallel group."""
+def bn_stats_sync(x, mode, period, dist, running_mean=None, running_var=None, momentum=-1.0, also=()):
+    """bn_stats with the (sum, sum of squares) all-reduced over the data-parallel group. `also`: further (running_mean,
+    running_var, momentum) triples to update from the SAME statistics (two BatchNorms fed by one tensor, model.py:239-240:
+    one pass over x and one all-reduce instead of two)."""
     _chk(x, torch.float32)
     rows, cols = x.shape
     ch = period if mode == 0 else cols
@@ -327,6 +335,9 @@ def bn_stats_sync(x, mode, period, dist, running_mean=None, running_var=None, mo
     var = torch.empty(ch, dtype=torch.float32, device=x.device)
     _lib.check(L.mla_bn_stats_finish(_p(sums), ch, float(count), _p(mean), _p(var), _p(running_mean), _p(running_var),
                                      float(momentum), _lib.stream_ptr()))
+    for rm, rv, mom in also:
+        scratch_m, scratch_v = torch.empty_like(mean), torch.empty_like(var)
+        _lib.check(L.mla_bn_stats_finish(_p(sums), ch, float(count), _p(scratch_m), _p(scratch_v), _p(rm), _p(rv), float(mom), _lib.stream_ptr()))
     return mean, var
 
 

@@ -171,6 +171,10 @@ int mla_linear(const void* a, int64_t lda, const void* w, int64_t ldw, const flo
 int mla_linear_splitk(const float* a, int64_t lda, const float* w, int64_t ldw, const float* bias, float* out,
                       int64_t ldo, int64_t M, int64_t N, int64_t K, int relu, int splits, float* workspace,
                       int64_t workspace_floats, mla_stream_t stream);
+/* nn.Linear with a NARROW output (N <= 16; model.py:230 fcv: 600 -> 10): one pass over `a`, 16 lanes per row, weights in LDS.
+ * f32; K % 4 == 0, rows 16-byte aligned, K * N * 4 <= 64 KiB. Every row is computed the same way whatever M. */
+int mla_linear_narrow(const float* a, int64_t lda, const float* w, int64_t ldw, const float* bias, float* out,
+                      int64_t ldo, int64_t M, int64_t N, int64_t K, mla_stream_t stream);
 /* Same contract in f32 without alignment requirements, for tiny layers (model.py:255 fc). */
 int mla_linear_small(const float* a, int64_t lda, const float* w, int64_t ldw, const float* bias,
                      float* out, int64_t ldo, int64_t M, int64_t N, int64_t K, mla_stream_t stream);

@@ -335,3 +335,19 @@ def test_stream_waveforms_overlapped_uploads(model, W):
         assert list(ens.stream_waveforms([])) == []
         with pytest.raises(AssertionError):
             list(ens.stream_waveforms([torch.zeros(2, 160000)]))
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 10, 600), (17, 1, 4), (1030, 16, 1024), (10240, 10, 600), (333, 7, 128)])
+def test_linear_narrow_matches_float64_and_is_batch_independent(ops, W, M, N, K):
+    """mla_linear_narrow (the attention modules' fcv, model.py:230: N <= 16): against float64, and a row alone == the same row
+    inside the batch, bit for bit (each row is reduced by its own 16 lanes in a fixed order)."""
+    a = torch.from_numpy(W.uniform(43, 1, M * K)).reshape(M, K).cuda()
+    w = (torch.from_numpy(W.uniform(43, 2, N * K)).reshape(N, K) * (3.0 / K) ** 0.5).cuda()
+    b = torch.from_numpy(W.uniform(43, 3, N)).cuda()
+    got = ops.linear(a, w, b)
+    ref = F.linear(a.double().cpu(), w.double().cpu(), b.double().cpu())
+    assert tuple(got.shape) == (M, N) and rel_err(got.cpu(), ref) < 2e-6
+    one = ops.linear(a[M // 2:M // 2 + 1].contiguous(), w, b)
+    assert torch.equal(one[0], got[M // 2])
+    nob = ops.linear(a, w, None)
+    assert rel_err(nob.cpu(), ref - b.double().cpu()) < 2e-6
