@@ -86,6 +86,7 @@ def lib():
         L.mla_cross_entropy.argtypes = [vp, i64, vp, i64, ci, cf, vp, vp, i64, vp, vp]
         L.mla_adam_step.argtypes = [vp, vp, vp, vp, i64, cf, cf, cf, cf, i64, vp]
         L.mla_conv3x3.argtypes = [vp, vp, vp, vp, i64, ci, ci, ci, ci, ci, ci, ci, vp]
+        L.mla_conv3x3_train.argtypes = [vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, ci, vp]
         L.mla_conv_repack_dgrad.argtypes = [vp, i64, i64, vp, vp]
         L.mla_maxpool2x2.argtypes = [vp, vp, i64, ci, ci, ci, vp]
         L.mla_relu_pool_bwd.argtypes = [vp, vp, vp, i64, ci, ci, ci, ci, vp]

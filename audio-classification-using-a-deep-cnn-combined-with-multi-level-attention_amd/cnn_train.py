@@ -8,7 +8,7 @@ train.py:96-97 made the CNN trainable). NHWC. Two arithmetic modes, chosen by th
   loss scaling). The bf16 weight copies are re-derived from the masters after every Adam step.
 
 Forward keeps, per conv layer, its input and its pre-pool post-ReLU output; the pooled layers
-run as conv (pool = 0) + mla_maxpool2x2 so that the pool/ReLU backward can route gradients to
+run mla_conv3x3_train, which writes the pre-pool activation AND its max-pool, so that the pool/ReLU backward can route gradients to
 the first maximum of each window. Backward per layer: mla_relu_pool_bwd -> dZ (+ db on the way); mla_conv_wgrad
 (dW); mla_conv3x3 with flipped/transposed weights (dgrad). The three Linear
 layers use the MFMA GEMM on transposed copies, as the MLA head does."""
@@ -43,9 +43,12 @@ def forward(cnn_model, x, precision="f32"):
     for layer in range(2, 7):
         cin, cout, H, W_, pooled = GEOM[layer]
         c = convs[layer - 1]
-        a = ops.conv3x3(cur, packed[layer - 2], c.bias.detach(), cout, pool=False, act=True)
+        if pooled:              # one kernel writes the kept pre-pool activation and the pooled one
+            a, nxt = ops.conv3x3_train(cur, packed[layer - 2], c.bias.detach(), cout)
+        else:
+            a = nxt = ops.conv3x3(cur, packed[layer - 2], c.bias.detach(), cout, pool=False, act=True)
         tape["layers"][layer] = (cur, a)
-        cur = ops.maxpool2x2(a) if pooled else a
+        cur = nxt
     h = cur.reshape(cur.shape[0], -1)
     tape["fc"] = []
     if fcs:

@@ -331,14 +331,24 @@ __global__ __launch_bounds__(256) void conv1_bwd_bf16_kernel(const float* __rest
             red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ void conv1_bwd_finish_bf16_kernel(const float* __restrict__ partial, int blocks, float* __restrict__ dw, float* __restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;           // 0 .. 639: (cg, c, k)
-    if (i >= 640) return;
+// one workgroup per (cg, c, k): the partials of all blocks are summed by 256 lanes and a fixed tree (it used to be one serial
+// loop over the 1 024 blocks per output: 0.42 ms of the finetune step)
+__global__ __launch_bounds__(256) void conv1_bwd_finish_bf16_kernel(const float* __restrict__ partial, int blocks, float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ double part[256];
+    const int i = blockIdx.x;                                      // 0 .. 639: (cg, c, k)
     const int cg = i / 80, rem = i % 80, c = rem / 10, k = rem % 10;
     double s = 0.0;
-    for (int b = 0; b < blocks; ++b) s += partial[(size_t(b) * 8 + cg) * 80 + rem];
-    if (k < 9) dw[(cg * 8 + c) * 9 + k] = float(s);
-    else db[cg * 8 + c] = float(s);
+    for (int b = threadIdx.x; b < blocks; b += 256) s += partial[(size_t(b) * 8 + cg) * 80 + rem];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (int(threadIdx.x) < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (k < 9) dw[(cg * 8 + c) * 9 + k] = float(part[0]);
+        else db[cg * 8 + c] = float(part[0]);
+    }
 }
 
 // ------------------------------------------------------------------- Linear-backward helpers ---
@@ -463,7 +473,7 @@ extern "C" int mla_conv1_bwd_bf16(const float* x, const float* w, const float* b
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(conv1_bwd_bf16_kernel, dim3(blocks, 8), dim3(256), 0, s, x, w, bias, static_cast<const bf16_t*>(d_pooled), n_pix, workspace);
     MLA_LAUNCH_OK("conv1_bwd_bf16");
-    hipLaunchKernelGGL(conv1_bwd_finish_bf16_kernel, dim3(3), dim3(256), 0, s, workspace, blocks, dw, db);
+    hipLaunchKernelGGL(conv1_bwd_finish_bf16_kernel, dim3(640), dim3(256), 0, s, workspace, blocks, dw, db);
     MLA_LAUNCH_OK("conv1_bwd_finish_bf16");
     return MLA_OK;
 }

@@ -153,7 +153,8 @@ template <typename C>
 __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const typename C::elem* __restrict__ in,
                                                                const typename C::elem* __restrict__ wgt,
                                                                const float* __restrict__ bias,
-                                                               typename C::elem* __restrict__ out, int n_img, int n_tiles) {
+                                                               typename C::elem* __restrict__ out, int n_img, int n_tiles,
+                                                               typename C::elem* __restrict__ prepool) {
     using T = typename C::elem;
     constexpr int PER = Elem<T>::kPerChunk;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -439,6 +440,21 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
         // accumulators); one vector store per pixel.
         {
             if (C::POOL) {
+                // training forward (mla_conv3x3_train): the pre-pool post-ReLU activation is kept as well -- the pool / ReLU backward
+                // routes gradients with it -- so that the pooled layers need no separate max-pool pass over a tensor just written
+                if (!C::SPLIT && prepool) {
+                    _Pragma("unroll") for (int i = 0; i < kMS; ++i) {
+                        const int y = y_tile + l_y0 + i;
+                        _Pragma("unroll") for (int e = 0; e < 4; ++e) {
+                            float v[C::NS];
+                            _Pragma("unroll") for (int j = 0; j < C::NS; ++j) v[j] = fmaxf(acc[i][j][e], 0.f);
+                            const int rr = 4 * q + e;
+                            const int img = img0 + (C::SEGW == 8 ? (rr >> 3) : 0);
+                            const int x = C::SEGW == 8 ? (rr & 7) : ((C::SEGS == 2 ? wm * 16 : 0) + rr);
+                            if (img < n_img) store_vec<T, C::NS>(prepool + ((size_t(img) * C::H + y) * C::W + x) * C::COUT + nb, v);
+                        }
+                    }
+                }
                 _Pragma("unroll") for (int ip = 0; ip < kMS / 2; ++ip) {
                     float p0[C::NS], p1[C::NS];
                     _Pragma("unroll") for (int j = 0; j < C::NS; ++j) {
@@ -650,7 +666,7 @@ __global__ void widen_kernel(const bf16_t* __restrict__ in, float* __restrict__ 
 }
 
 template <typename C>
-int launch_conv(const void* in, const void* w, const float* bias, void* out, int64_t n_img, hipStream_t s) {
+int launch_conv(const void* in, const void* w, const float* bias, void* out, int64_t n_img, hipStream_t s, void* prepool = nullptr) {
     using T = typename C::elem;
     auto kern = conv3x3_kernel<C>;
     MLA_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -667,7 +683,7 @@ int launch_conv(const void* in, const void* w, const float* bias, void* out, int
     if (gx < C::TILES_Y) gx = C::TILES_Y;
     if (gx > tiles || !C::PERSIST) gx = tiles;
     hipLaunchKernelGGL(kern, dim3(unsigned(gx), n_tiles_n), dim3(kThreads), C::LDS_BYTES, s,
-                       static_cast<const T*>(in), static_cast<const T*>(w), bias, static_cast<T*>(out), int(n_img), int(tiles));
+                       static_cast<const T*>(in), static_cast<const T*>(w), bias, static_cast<T*>(out), int(n_img), int(tiles), static_cast<T*>(prepool));
     MLA_LAUNCH_OK("conv3x3_kernel");
     return MLA_OK;
 }
@@ -711,10 +727,10 @@ __global__ void repack_dgrad_kernel(const float* __restrict__ w, float* __restri
 // fused pool (training keeps the pre-pool activations) and the five dgrad shapes; f32 (exact) and bf16
 template <typename T>
 int conv_generic(const void* in, const void* w, const float* bias, void* out, int64_t n, int H, int W, int cin, int cout,
-                 bool pool, bool act, hipStream_t s) {
+                 bool pool, bool act, hipStream_t s, void* prepool = nullptr) {
 #define MLA_CONV_CASE(CI, CO, HH, WW, PO, NS_, AC)                                                             \
     if (cin == CI && cout == CO && H == HH && W == WW && pool == PO && act == AC)                              \
-        return launch_conv<Cfg<T, CI, CO, HH, WW, PO, NS_, AC>>(in, w, bias, out, n, s);
+        return launch_conv<Cfg<T, CI, CO, HH, WW, PO, NS_, AC>>(in, w, bias, out, n, s, prepool);
     MLA_CONV_CASE(64, 128, 48, 32, true, 2, true)
     MLA_CONV_CASE(128, 256, 24, 16, false, 4, true)
     MLA_CONV_CASE(256, 256, 24, 16, true, 4, true)
@@ -750,6 +766,18 @@ extern "C" int mla_conv3x3(const void* in, const void* w_packed, const float* bi
     if (dtype == MLA_BF16)
         return conv_generic<bf16_t>(in, w_packed, bias, out, n, H, W, cin, cout, pool != 0, act != 0, static_cast<hipStream_t>(stream));
     return conv_generic<float>(in, w_packed, bias, out, n, H, W, cin, cout, pool != 0, act != 0, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mla_conv3x3_train(const void* in, const void* w_packed, const float* bias, void* out_prepool, void* out_pooled, int64_t n,
+                                 int H, int W, int cin, int cout, int dtype, mla_stream_t stream) {
+    MLA_REQUIRE(n >= 0, MLA_E_ARG, "n %lld", (long long)n);
+    if (n == 0) return MLA_OK;
+    MLA_REQUIRE(in && w_packed && bias && out_prepool && out_pooled, MLA_E_ARG, "null conv buffers");
+    MLA_REQUIRE(mla::aligned(in, 16) && mla::aligned(w_packed, 16) && mla::aligned(out_prepool, 16), MLA_E_ARG, "conv buffers must be 16-byte aligned");
+    MLA_REQUIRE(dtype == MLA_F32 || dtype == MLA_BF16, MLA_E_DTYPE, "conv3x3_train dtype %d", dtype);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == MLA_BF16) return conv_generic<bf16_t>(in, w_packed, bias, out_pooled, n, H, W, cin, cout, true, true, s, out_prepool);
+    return conv_generic<float>(in, w_packed, bias, out_pooled, n, H, W, cin, cout, true, true, s, out_prepool);
 }
 
 extern "C" int mla_conv_repack_dgrad(const float* w_oihw, int64_t cout, int64_t cin, float* out, mla_stream_t stream) {

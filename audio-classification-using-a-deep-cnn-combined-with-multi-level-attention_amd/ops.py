@@ -462,6 +462,17 @@ def conv3x3(x, w_packed, b, cout, pool, act):
     return out
 
 
+def conv3x3_train(x, w_packed, b, cout):
+    """Training forward of a pooled layer: (pre-pool post-ReLU activation, its 2x2 max-pool) from one kernel."""
+    _chk(x); _chk(w_packed, x.dtype)
+    n, H, W_, cin = x.shape
+    a = torch.empty((n, H, W_, cout), dtype=x.dtype, device=x.device)
+    pooled = torch.empty((n, H // 2, W_ // 2, cout), dtype=x.dtype, device=x.device)
+    _lib.check(_timed("conv3x3_%d_%d" % (cin, cout), _lib.lib().mla_conv3x3_train, _p(x), _p(w_packed), _p(b), _p(a), _p(pooled), n, H, W_,
+                      cin, cout, DT[x.dtype], _lib.stream_ptr()))
+    return a, pooled
+
+
 def repack_dgrad(w, dtype=torch.float32):
     """(Cout, Cin, 3, 3) f32 -> (Cin, 9, Cout) flipped, in `dtype`: weights of the transposed convolution."""
     _chk(w, torch.float32)

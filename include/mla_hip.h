@@ -275,6 +275,11 @@ int mla_cross_entropy(const float* x, int64_t ldx, const int64_t* labels, int64_
  * (activations and repacked weights in that type, f32 accumulation). */
 int mla_conv3x3(const void* in, const void* w_packed, const float* bias, void* out, int64_t n, int H, int W,
                 int cin, int cout, int pool, int act, int dtype, mla_stream_t stream);
+/* Training forward of a POOLED layer (conv2 / conv4 / conv6 shapes): bias + ReLU, writes BOTH the pre-pool activation
+ * (n, H, W, cout) -- kept for the pool / ReLU backward -- and its 2x2 max-pool (n, H/2, W/2, cout) from one pass (the separate
+ * mla_maxpool2x2 over the tensor just written is not needed). dtype MLA_F32 or MLA_BF16. */
+int mla_conv3x3_train(const void* in, const void* w_packed, const float* bias, void* out_prepool, void* out_pooled, int64_t n,
+                      int H, int W, int cin, int cout, int dtype, mla_stream_t stream);
 /* (Cout, Cin, 3, 3) -> (Cin, 9, Cout), taps flipped: weights of the dgrad convolution. */
 int mla_conv_repack_dgrad(const float* w_oihw, int64_t cout, int64_t cin, float* out, mla_stream_t stream);
 /* nn.MaxPool2d(2, 2) on a kept NHWC activation (n, H, W, C) -> (n, H/2, W/2, C). */

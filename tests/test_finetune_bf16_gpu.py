@@ -209,3 +209,19 @@ def test_finetune_bf16_curve_against_the_reference_golden(golden, mk, W):
                 d.mask = masks["mla.embedded_mappings.%d.dropouts.%d" % (lvl, j)]
         l2.append(float(step2(x.cuda(), y.cuda())[0]))
     assert l2 == losses[:2]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,H,Wd", [(64, 128, 48, 32), (256, 256, 24, 16), (512, 512, 12, 8)])
+def test_conv3x3_train_writes_prepool_and_pooled(ops, W, dtype, cin, cout, H, Wd):
+    """mla_conv3x3_train == the un-pooled forward followed by mla_maxpool2x2, bit for bit (same accumulators, the pool is taken on
+    the stored values' source registers; bf16: max commutes with the rounding because rounding is monotone)."""
+    n = 3
+    x = rnd(W, 91, cin, (n, H, Wd, cin), -0.5, 1.0).to(dtype).cuda()
+    w = (rnd(W, 92, cout, (cout, cin, 3, 3)) * (6.0 / (9 * cin)) ** 0.5).cuda()
+    b = (rnd(W, 93, cout, (cout,)) * 0.1).cuda()
+    wp = ops.repack_conv_weight(w, dtype)
+    a_ref = ops.conv3x3(x, wp, b, cout, pool=False, act=True)
+    p_ref = ops.maxpool2x2(a_ref)
+    a, p = ops.conv3x3_train(x, wp, b, cout)
+    assert torch.equal(a, a_ref) and torch.equal(p, p_ref)
