@@ -130,17 +130,33 @@ __global__ __launch_bounds__(256) void bias_slots_finish8_kernel(const double* _
 }
 
 // ------------------------------------------------------------------------------------ wgrad ---
+// One persistent 8-wave workgroup per CU; waves as WCO x WCI, each 32 co x 32 ci x 9 taps (144 accumulator registers); workgroup
+// tile (32 WCO) co x (32 WCI) ci. Work items = (image, band of TH rows) of this workgroup's image split. Per item the dZ band and
+// the input patch with halo are staged by LDS-DMA (buffer_load ... lds) into one of TWO LDS images, so the transfer of item i+1 runs
+// under the MFMAs of item i (the first version staged synchronously through registers: 600 TFLOP/s; this one: see DESIGN.md).
+// LDS image: per 64-channel block, [pixel][128 B] rows (patch rows pitched at a multiple of 8 pixels), 16-byte chunk c of row r
+// stored at chunk c ^ (((r >> 1) & 3) << 1): the transposing reads of a 32-lane half cover 8 CONSECUTIVE pixel rows x 32 B, which
+// this XOR spreads over the 8 distinct 32-byte slots of a 256-byte bank row pair for every tap shift; because every (k-step, tap
+// row) offset is a multiple of 8 rows the key depends on the lane and the tap's kx only -- 8 address registers per lane, all other
+// offsets are immediates. The DMA applies the same involution on the source side (a piece = 8 rows x 8 chunks in lane order). Out-of-image halo pixels carry an out-of-range offset: the range check drops those lanes, so the
+// x-halo columns are zeroed once and the y-halo rows whenever a first / last band is staged.
 template <int CIN, int COUT, int H, int W>
 struct WBCfg {
+    static constexpr int WCO = CIN >= 128 ? 2 : 4, WCI = 8 / WCO;     // conv2's wgrad (64 input channels): 128 co x 64 ci
+    static constexpr int TCO = 32 * WCO, TCI = 32 * WCI;              // workgroup tile
+    static constexpr int CBZ = TCO / 64, CBA = TCI / 64;              // 64-channel blocks per image
     static constexpr int TH = W == 32 ? 4 : (W == 16 ? 8 : 12);        // image rows per staged band
     static constexpr int KSTEPS = TH * W / 32;                         // 32 pixels per MFMA k-step
     static constexpr int BANDS = H / TH;
     static constexpr int PW = W + 2, PH = TH + 2;
-    static constexpr int PITCH = 160;                                  // bytes per staged pixel: 64 bf16 + 32 B (bank spread)
-    static constexpr int Z_BYTES = TH * W * PITCH, A_BYTES = PH * PW * PITCH;
-    static constexpr int LDS_BYTES = Z_BYTES + A_BYTES;
-    static constexpr int TILES_CO = COUT / 64, TILES_CI = CIN / 64;
-    static_assert(H % TH == 0 && (TH * W) % 32 == 0 && COUT % 64 == 0 && CIN % 64 == 0 && 2 * LDS_BYTES <= 160 * 1024, "wgrad tiling");
+    static constexpr int PWP = (PW + 7) / 8 * 8;                       // patch row pitch in pixel rows: a multiple of 8, so that the
+                                                                       // swizzle key of a pixel depends on its column only
+    static constexpr int Z_PIX = TH * W, A_PIX = PH * PWP;             // pixel rows per block image (whole DMA pieces)
+    static constexpr int Z_BYTES = CBZ * Z_PIX * 128, A_BYTES = CBA * A_PIX * 128;
+    static constexpr int BUF_BYTES = Z_BYTES + A_BYTES;
+    static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+    static constexpr int TILES_CO = COUT / TCO, TILES_CI = CIN / TCI;
+    static_assert(H % TH == 0 && Z_PIX % 32 == 0 && COUT % TCO == 0 && CIN % TCI == 0 && LDS_BYTES <= 160 * 1024, "wgrad tiling");
 };
 
 __device__ __forceinline__ s16x4 tr_read(const char* p) {
@@ -149,80 +165,127 @@ __device__ __forceinline__ s16x4 tr_read(const char* p) {
 __device__ __forceinline__ bf16x8 frag_of(s16x4 lo, s16x4 hi) {
     return __builtin_bit_cast(bf16x8, s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w});
 }
-
 template <typename C, int CIN, int COUT, int H, int W>
-__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ ain,
+__global__ __launch_bounds__(512, 2) void wgrad_bf16_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ ain,
                                                             float* __restrict__ partial, int n_img) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sZ = smem;
-    char* sA = smem + C::Z_BYTES;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave / C::WCI, wc = wave % C::WCI;
     const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;      // transposing read: lane 4 q4 + p4 of its group
     const int r = lane & 15, q = lane >> 4;                                  // supplies pixel row q4, channels 4 p4 .. 4 p4 + 3
-    const int co0 = (blockIdx.x / C::TILES_CI) * 64, ci0 = (blockIdx.x % C::TILES_CI) * 64;
+    const int co0 = (blockIdx.x / C::TILES_CI) * C::TCO, ci0 = (blockIdx.x % C::TILES_CI) * C::TCI;
     const int split = blockIdx.y, splits = gridDim.y;
 
     // pixel (y, x) of k-step s, half h (elements 4h .. 4h+3 of the fragment), lane group g, row q4 of the 4-pixel block:
     //   W = 32: y = s,               x = 16 h + 4 g + q4      W = 16: y = 2 s + h, x = 4 g + q4
     //   W = 8 : y = 4 s + 2 h + (g >> 1), x = 4 (g & 1) + q4
-    // per lane: ly / lx = the (g, q4)-dependent part; the (s, h) part is a compile-time constant
     const int ly = W == 8 ? (g >> 1) : 0;
     const int lx = (W == 8 ? 4 * (g & 1) : 4 * g) + q4;
-    const int zlane = (ly * W + lx) * C::PITCH + 8 * p4;                    // + channel tile * 32 B + (s, h) pixel offset
-    const int alane = (ly * C::PW + lx) * C::PITCH + 8 * p4;
     auto sh_y = [](int s, int h) { return W == 32 ? s : (W == 16 ? 2 * s + h : 4 * s + 2 * h); };
     auto sh_x = [](int h) { return W == 32 ? 16 * h : 0; };
+    // this wave's 32 co = 16-channel tiles 2 wr, 2 wr + 1 of the workgroup tile (ci: 2 wc, 2 wc + 1): 64-channel block and 32-byte slot
+    // of each. Per-lane byte offsets of the transposing reads; everything that depends on (k-step, half, ky) is a multiple of 8 rows.
+    int zbase[2], abase[3][2];
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {
+        const int tile = 2 * wr + i, chunk = 2 * (tile & 3) + (p4 >> 1), key = (lx >> 1) & 3;
+        zbase[i] = (tile >> 2) * C::Z_PIX * 128 + (ly * W + lx) * 128 + 16 * (chunk ^ (key << 1)) + 8 * (p4 & 1);
+    }
+    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {
+            const int tile = 2 * wc + j, chunk = 2 * (tile & 3) + (p4 >> 1), key = ((lx + kx) >> 1) & 3;
+            abase[kx][j] = (tile >> 2) * C::A_PIX * 128 + (ly * C::PWP + lx + kx) * 128 + 16 * (chunk ^ (key << 1)) + 8 * (p4 & 1);
+        }
+
+    constexpr uint32_t IMG_Z = uint32_t(H) * W * COUT * 2, IMG_A = uint32_t(H) * W * CIN * 2;
+    // DMA of one item into buffer `buf`: pieces of 8 pixel rows x 128 B, wave `wave` takes pieces wave, wave + 8, ...
+    auto stage = [&](int img, int band, int buf) {
+        char* base = smem + buf * C::BUF_BYTES;
+        const int y0 = band * C::TH;
+        const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dz) + size_t(img) * H * W * COUT, 0, IMG_Z, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(ain) + size_t(img) * H * W * CIN, 0, IMG_A, 0x00020000);
+        const int prow = lane >> 3, slot = lane & 7;
+        constexpr int ZP = C::CBZ * C::Z_PIX / 8, AP = C::CBA * C::A_PIX / 8;
+        _Pragma("unroll") for (int p = 0; p < (ZP + 7) / 8; ++p) {
+            const int piece = wave + 8 * p;
+            if (piece < ZP) {
+                const int blk = piece / (C::Z_PIX / 8), row = (piece % (C::Z_PIX / 8)) * 8 + prow;
+                const int chunk = slot ^ (((row >> 1) & 3) << 1);
+                const int voff = ((y0 * W + row) * COUT + co0 + blk * 64 + chunk * 8) * 2;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (__attribute__((address_space(3))) void*)(base + piece * 1024), 16, voff, 0, 0, 0);
+            }
+        }
+        char* pbase = base + C::Z_BYTES;
+        _Pragma("unroll") for (int p = 0; p < (AP + 7) / 8; ++p) {
+            const int piece = wave + 8 * p;
+            if (piece < AP) {
+                const int blk = piece / (C::A_PIX / 8), row = (piece % (C::A_PIX / 8)) * 8 + prow;
+                const int xh = row % C::PWP, yh = row / C::PWP;
+                const int gy = y0 + yh - 1, gx = xh - 1;
+                const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;               // also false for the pitch padding (xh >= PW)
+                const int chunk = slot ^ (((row >> 1) & 3) << 1);
+                const int voff = ok ? ((gy * W + gx) * CIN + ci0 + blk * 64 + chunk * 8) * 2 : 0x7fffff00;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(pbase + piece * 1024), 16, voff, 0, 0, 0);
+            }
+        }
+        // out-of-image y-halo rows of a first / last band: the DMA dropped them, a previous item may have left data there
+        if (C::BANDS > 1 && (band == 0 || band == C::BANDS - 1)) {
+            const int yh = band == 0 ? 0 : C::PH - 1;
+            for (int i = t; i < C::CBA * C::PWP * 8; i += 512) {
+                const int blk = i / (C::PWP * 8), rem = i % (C::PWP * 8);
+                *reinterpret_cast<u32x4*>(pbase + (blk * C::A_PIX + yh * C::PWP + rem / 8) * 128 + (rem & 7) * 16) = zero16();
+            }
+        }
+    };
 
     f32x4 acc[2][2][9];
     _Pragma("unroll") for (int i = 0; i < 2; ++i)
         _Pragma("unroll") for (int j = 0; j < 2; ++j)
             _Pragma("unroll") for (int k = 0; k < 9; ++k) acc[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int img = split; img < n_img; img += splits) {
-        for (int band = 0; band < C::BANDS; ++band) {
-            const int y0 = band * C::TH;
-            __syncthreads();
-            // stage dZ rows y0 .. y0+TH-1 (64 output channels) and the input patch with halo (64 input channels)
-            for (int p = t; p < C::TH * W * 8; p += 256) {
-                const int ch = p & 7, pix = p >> 3;
-                const int x = pix % W, y = pix / W;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(dz + ((size_t(img) * H + y0 + y) * W + x) * COUT + co0 + ch * 8);
-                *reinterpret_cast<u32x4*>(sZ + pix * C::PITCH + ch * 16) = v;
+    // zero both patch images once: the x-halo columns (and, for single-band shapes, the y-halo rows) are never written by the DMA
+    for (int i = t; i < 2 * C::A_BYTES / 16; i += 512) {
+        const int buf = i / (C::A_BYTES / 16), off = i % (C::A_BYTES / 16);
+        *reinterpret_cast<u32x4*>(smem + buf * C::BUF_BYTES + C::Z_BYTES + off * 16) = zero16();
+    }
+    __syncthreads();
+
+    const int n_mine = split < n_img ? (n_img - split + splits - 1) / splits : 0;
+    const int n_items = n_mine * C::BANDS;
+    if (n_items > 0) stage(split, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int it = 0; it < n_items; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < n_items) {
+            const int ni = it + 1;
+            stage(split + (ni / C::BANDS) * splits, ni % C::BANDS, buf ^ 1);     // lands under this item's MFMAs
+        }
+        const char* sZ = smem + buf * C::BUF_BYTES;
+        const char* sA = sZ + C::Z_BYTES;
+        _Pragma("unroll") for (int s = 0; s < C::KSTEPS; ++s) {
+            bf16x8 za[2];
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {
+                s16x4 part[2];
+                _Pragma("unroll") for (int h = 0; h < 2; ++h)
+                    part[h] = tr_read(sZ + zbase[i] + (sh_y(s, h) * W + sh_x(h)) * 128);
+                za[i] = frag_of(part[0], part[1]);
             }
-            for (int p = t; p < C::PH * C::PW * 8; p += 256) {
-                const int ch = p & 7, pix = p >> 3;
-                const int xh = pix % C::PW, yh = pix / C::PW;
-                const int gy = y0 + yh - 1, gx = xh - 1;
-                u32x4 v = zero16();
-                if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                    v = *reinterpret_cast<const u32x4*>(ain + ((size_t(img) * H + gy) * W + gx) * CIN + ci0 + ch * 8);
-                *reinterpret_cast<u32x4*>(sA + pix * C::PITCH + ch * 16) = v;
-            }
-            __syncthreads();
-            _Pragma("unroll") for (int s = 0; s < C::KSTEPS; ++s) {
-                bf16x8 za[2];
-                _Pragma("unroll") for (int i = 0; i < 2; ++i) {
-                    s16x4 part[2];
-                    _Pragma("unroll") for (int h = 0; h < 2; ++h)
-                        part[h] = tr_read(sZ + zlane + (sh_y(s, h) * W + sh_x(h)) * C::PITCH + (wr * 2 + i) * 32);
-                    za[i] = frag_of(part[0], part[1]);
-                }
-                _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {
-                    bf16x8 ab[3][2];
-                    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)
-                        _Pragma("unroll") for (int j = 0; j < 2; ++j) {
-                            s16x4 part[2];
-                            _Pragma("unroll") for (int h = 0; h < 2; ++h)
-                                part[h] = tr_read(sA + alane + ((sh_y(s, h) + ky) * C::PW + sh_x(h) + kx) * C::PITCH + (wc * 2 + j) * 32);
-                            ab[kx][j] = frag_of(part[0], part[1]);
-                        }
-                    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)
-                        _Pragma("unroll") for (int i = 0; i < 2; ++i)
-                            _Pragma("unroll") for (int j = 0; j < 2; ++j)
-                                acc[i][j][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[i], ab[kx][j], acc[i][j][ky * 3 + kx], 0, 0, 0);
-                }
+            _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {
+                bf16x8 ab[3][2];
+                _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j) {
+                        s16x4 part[2];
+                        _Pragma("unroll") for (int h = 0; h < 2; ++h)
+                            part[h] = tr_read(sA + abase[kx][j] + ((sh_y(s, h) + ky) * C::PWP + sh_x(h)) * 128);
+                        ab[kx][j] = frag_of(part[0], part[1]);
+                    }
+                _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i)
+                        _Pragma("unroll") for (int j = 0; j < 2; ++j)
+                            acc[i][j][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[i], ab[kx][j], acc[i][j][ky * 3 + kx], 0, 0, 0);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next item has landed before the barrier publishes it
+        __syncthreads();                                       // ... and everybody is done reading this one
     }
     // partial[split][co][tap][ci]; C/D layout: col = lane & 15 (ci), row = 4 (lane >> 4) + reg (co)
     float* out = partial + size_t(split) * COUT * 9 * CIN;
@@ -256,13 +319,15 @@ template <int CIN, int COUT, int H, int W>
 int launch_wgrad_bf16(const bf16_t* dz, const bf16_t* ain, int64_t n, float* partial, int64_t partial_floats, float* dw, hipStream_t s) {
     using C = WBCfg<CIN, COUT, H, W>;
     const int tiles = C::TILES_CO * C::TILES_CI;
-    int splits = (768 + tiles - 1) / tiles;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int splits = cus / tiles < 1 ? 1 : cus / tiles;           // one persistent workgroup per CU
     if (splits > n) splits = int(n);
     const int64_t need = int64_t(splits) * COUT * 9 * CIN;
     MLA_REQUIRE(partial_floats >= need, MLA_E_ARG, "wgrad workspace too small: %lld < %lld floats", (long long)partial_floats, (long long)need);
     auto kern = wgrad_bf16_kernel<C, CIN, COUT, H, W>;
     MLA_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), C::LDS_BYTES, s, dz, ain, partial, int(n));
+    hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(512), C::LDS_BYTES, s, dz, ain, partial, int(n));
     MLA_LAUNCH_OK("wgrad_bf16_kernel");
     hipLaunchKernelGGL(wgrad_reduce_bf16_kernel, dim3(1024), dim3(256), 0, s, partial, splits, COUT, CIN, dw);
     MLA_LAUNCH_OK("wgrad_reduce_bf16_kernel");
