@@ -147,6 +147,7 @@ struct WBCfg {
     static constexpr int CBZ = TCO / 64, CBA = TCI / 64;              // 64-channel blocks per image
     static constexpr int TH = W == 32 ? 4 : (W == 16 ? 8 : 12);        // image rows per staged band
     static constexpr int KSTEPS = TH * W / 32;                         // 32 pixels per MFMA k-step
+    static constexpr bool UNROLL = !(W == 32 || (CIN == 512 && COUT == 512));
     static constexpr int BANDS = H / TH;
     static constexpr int PW = W + 2, PH = TH + 2;
     static constexpr int PWP = (PW + 7) / 8 * 8;                       // patch row pitch in pixel rows: a multiple of 8, so that the
@@ -172,8 +173,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_kernel(const bf16_t* __rest
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave / C::WCI, wc = wave % C::WCI;
     const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;      // transposing read: lane 4 q4 + p4 of its group
     const int r = lane & 15, q = lane >> 4;                                  // supplies pixel row q4, channels 4 p4 .. 4 p4 + 3
-    const int co0 = (blockIdx.x / C::TILES_CI) * C::TCO, ci0 = (blockIdx.x % C::TILES_CI) * C::TCI;
-    const int split = blockIdx.y, splits = gridDim.y;
+    // blockIdx.x = image split (fastest: consecutive workgroups are dealt round-robin over the 8 XCDs, so all tiles of one split --
+    // which read the SAME images -- share an XCD's L2 and each image leaves HBM once, not once per XCD), blockIdx.y = (co, ci) tile
+    const int co0 = (blockIdx.y / C::TILES_CI) * C::TCO, ci0 = (blockIdx.y % C::TILES_CI) * C::TCI;
+    const int split = blockIdx.x, splits = gridDim.x;
 
     // pixel (y, x) of k-step s, half h (elements 4h .. 4h+3 of the fragment), lane group g, row q4 of the 4-pixel block:
     //   W = 32: y = s,               x = 16 h + 4 g + q4      W = 16: y = 2 s + h, x = 4 g + q4
@@ -261,7 +264,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_kernel(const bf16_t* __rest
         }
         const char* sZ = smem + buf * C::BUF_BYTES;
         const char* sA = sZ + C::Z_BYTES;
-        _Pragma("unroll") for (int s = 0; s < C::KSTEPS; ++s) {
+        // k-step body. Whether the loop over the band's k-steps is unrolled is a per-shape choice (C::UNROLL): unrolled, every LDS
+        // offset is an immediate but hipcc keeps more addresses live (spills at W = 32 and for 512 -> 512: 611 -> 941 and
+        // 981 -> 1200 TFLOP/s when NOT unrolled); the other three shapes lose 7-11 % without it
+        auto kstep = [&](int s) {
             bf16x8 za[2];
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {
                 s16x4 part[2];
@@ -283,6 +289,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_kernel(const bf16_t* __rest
                         _Pragma("unroll") for (int j = 0; j < 2; ++j)
                             acc[i][j][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[i], ab[kx][j], acc[i][j][ky * 3 + kx], 0, 0, 0);
             }
+        };
+        if constexpr (C::UNROLL) {
+            _Pragma("unroll") for (int s = 0; s < C::KSTEPS; ++s) kstep(s);
+        } else {
+            _Pragma("unroll 1") for (int s = 0; s < C::KSTEPS; ++s) kstep(s);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next item has landed before the barrier publishes it
         __syncthreads();                                       // ... and everybody is done reading this one
@@ -327,7 +338,7 @@ int launch_wgrad_bf16(const bf16_t* dz, const bf16_t* ain, int64_t n, float* par
     MLA_REQUIRE(partial_floats >= need, MLA_E_ARG, "wgrad workspace too small: %lld < %lld floats", (long long)partial_floats, (long long)need);
     auto kern = wgrad_bf16_kernel<C, CIN, COUT, H, W>;
     MLA_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(512), C::LDS_BYTES, s, dz, ain, partial, int(n));
+    hipLaunchKernelGGL(kern, dim3(splits, tiles), dim3(512), C::LDS_BYTES, s, dz, ain, partial, int(n));
     MLA_LAUNCH_OK("wgrad_bf16_kernel");
     hipLaunchKernelGGL(wgrad_reduce_bf16_kernel, dim3(1024), dim3(256), 0, s, partial, splits, COUT, CIN, dw);
     MLA_LAUNCH_OK("wgrad_reduce_bf16_kernel");
