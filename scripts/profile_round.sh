@@ -20,4 +20,5 @@ python3 scripts/gemm_bench.py 10240 bf16 > gpurun_out/${TAG}_gemm_bench.txt 2>/d
 python3 scripts/gemm_bench.py 10240 f32 >> gpurun_out/${TAG}_gemm_bench.txt 2>/dev/null
 python3 scripts/fe_bench.py > gpurun_out/${TAG}_fe_bench.txt 2>/dev/null
 python3 scripts/train_bench.py > gpurun_out/${TAG}_train_bench.txt 2>/dev/null
+python3 scripts/wgrad_bench.py > gpurun_out/${TAG}_wgrad_bench.txt 2>/dev/null
 echo all done
