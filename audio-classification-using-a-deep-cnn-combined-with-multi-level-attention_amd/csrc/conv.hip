@@ -52,6 +52,18 @@ __device__ unsigned long long g_conv_stamps[8][2][8];
 #ifndef MLA_CONV_NARROW_PERSIST
 #define MLA_CONV_NARROW_PERSIST 0   // 1: conv2's bf16 inference configuration as one persistent workgroup per CU (A/B builds)
 #endif
+#ifndef MLA_CONV1_RAW_BARRIER
+#define MLA_CONV1_RAW_BARRIER 1
+#endif
+#ifndef MLA_CONV1_WAVES
+#define MLA_CONV1_WAVES 3
+#endif
+#ifndef MLA_CONV1_ROWS
+#define MLA_CONV1_ROWS 16            // input rows per workgroup tile of the patch-GEMM conv1 (must divide 96; measured 8: 0.87, 16: 0.43, 24 / 32 / 48: 0.56-0.73 ms)
+#endif
+#ifndef MLA_CONV1_GATHER
+#define MLA_CONV1_GATHER 0          // 1: bf16 conv1 through the round-1 gather kernel (A/B builds)
+#endif
 #ifndef MLA_CONV_DMA_LATE
 #define MLA_CONV_DMA_LATE 1
 #endif
@@ -534,7 +546,10 @@ __global__ __launch_bounds__(256, 4) void conv1_kernel(const TIN* __restrict__ x
         _Pragma("unroll") for (int k = 0; k < 3; ++k) {
             const int p = t + 256 * k, yh = p / 66, xh = p % 66;
             const int gy = y0 + yh - 1, gx = xh - 1;
-            pre[k] = (p < 660 && gy >= 0 && gy < 96 && gx >= 0 && gx < 64) ? load_elem<TIN>(x + (size_t(img) * 96 + gy) * 64 + gx) : 0.f;
+            // unconditional load from a clamped address + select (a conditional load is branched around and waited for one by one)
+            const int cy = gy < 0 ? 0 : (gy > 95 ? 95 : gy), cx = gx < 0 ? 0 : (gx > 63 ? 63 : gx);
+            const float v = load_elem<TIN>(x + (size_t(img) * 96 + cy) * 64 + cx);
+            pre[k] = (p < 660 && gy >= 0 && gy < 96 && gx >= 0 && gx < 64) ? v : 0.f;
         }
     };
     auto patch_write = [&]() {
@@ -638,6 +653,132 @@ __global__ __launch_bounds__(256, 4) void conv1_kernel(const TIN* __restrict__ x
         *reinterpret_cast<u32x4*>(dst + size_t(piece) * 16) = *reinterpret_cast<const u32x4*>(stage + p * ROW + c * 16);
     }
     __syncthreads();                                            // every wave is done with sX before the next patch lands
+    }
+}
+
+// ---- conv1, bf16 output: the layer as a K = 16 GEMM over 4 x 4 INPUT PATCHES (round 2) --------------------------------------
+// The four pre-pool outputs of a pooled pixel read the same 4 x 4 input patch (rows 2py-1 .. 2py+2, columns 2px-1 .. 2px+2), so
+//   pre[pos][ch] = sum_{k < 16} W'[pos][ch][k] * patch[k],   W'[(dy,dx)][ch][4 (dy+ky) + (dx+kx)] = w[ch][ky][kx], 0 elsewhere,
+// which is exactly one v_mfma_f32_32x32x16_bf16 per (position, 32 channels) with the WEIGHTS as the A operand (held in registers
+// for the workgroup's life) and 32 pooled pixels of one pooled row as the B operand: a lane's fragment is two patch rows of its
+// pixel = two ds_read2_b32 (the gather form above needs 8 ds_read_b32 per 16 PRE-pool pixels: 32x the LDS instructions), the 2 x 2
+// max-pool is an elementwise max over the four positions' accumulators, and with the weight rows permuted (MFMA row rho holds
+// channel 16 ((rho >> 2) & 1) + (rho & 3) + 4 (rho >> 3) of its 32) a lane ends up with 16 CONSECUTIVE channels of its pixel.
+// 8 MFMAs per 32 pooled pixels x 64 channels instead of 32 x 16x16x32. Accumulators start at the bias (max commutes with + b).
+template <typename TIN>
+__global__ __launch_bounds__(256, MLA_CONV1_WAVES) void conv1_patch_kernel(const TIN* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, bf16_t* __restrict__ out, int n_img) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    constexpr int TR = MLA_CONV1_ROWS;                          // input rows per tile (TR / 2 pooled rows, TR / 8 per wave)
+    constexpr int TPC = 96 / TR;                                // tiles per clip
+    constexpr int NP = (TR + 2) * 66;                           // staged input elements per tile
+    constexpr int NL = (NP + 255) / 256;                        // ... per thread
+    constexpr int PITCH = 68;                                   // bf16 per staged input row: 66 used, element (gy, gx) at column gx + 1
+    constexpr int ROW = 64 * 2 + 16;                            // bytes per pooled pixel in the output stage
+    __shared__ __attribute__((aligned(16))) uint16_t sX[(TR + 2) * PITCH];
+    __shared__ __attribute__((aligned(16))) char sOut[4 * 32 * ROW];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, px = lane & 31, h = lane >> 5;
+    const int n_tiles = n_img * TPC;
+
+    // A operand: W'[pos][channel(rho)][8 h + j] for rho = lane & 31, per position and 32-channel tile
+    bf16x8 wa[4][2];
+    f32x16 binit[2];
+    {
+        const int rho = px;
+        const int chl = 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);
+        _Pragma("unroll") for (int pos = 0; pos < 4; ++pos) {
+            const int dy = pos >> 1, dx = pos & 1;
+            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {
+                const int ch = mt * 32 + chl;
+                uint32_t pk[4];
+                _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {
+                    float v[2];
+                    _Pragma("unroll") for (int e = 0; e < 2; ++e) {
+                        const int k = 8 * h + 2 * jj + e, i = k >> 2, c = k & 3;          // patch row i, column c
+                        const int ky = i - dy, kx = c - dx;
+                        v[e] = (ky >= 0 && ky < 3 && kx >= 0 && kx < 3) ? w[ch * 9 + ky * 3 + kx] : 0.f;
+                    }
+                    pk[jj] = pack_bf16x2(v[0], v[1]);
+                }
+                wa[pos][mt] = __builtin_bit_cast(bf16x8, u32x4{pk[0], pk[1], pk[2], pk[3]});
+            }
+        }
+        // C/D: lane (col = pixel, hi = h) register reg <-> MFMA row (reg & 3) + 8 (reg >> 2) + 4 hi <-> channel 16 hi + reg of the tile
+        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)
+            _Pragma("unroll") for (int reg = 0; reg < 16; ++reg) binit[mt][reg] = bias[mt * 32 + 16 * h + reg];
+    }
+
+    // input rows y0-1 .. y0+TR, columns -1 .. 64 of one tile -> NL registers per thread, then LDS (bf16)
+    float pre[NL];
+    auto patch_load = [&](int tile) {
+        const int img = tile / TPC, y0 = (tile % TPC) * TR;
+        _Pragma("unroll") for (int k = 0; k < NL; ++k) {
+            const int p = t + 256 * k, yh = p / 66, xh = p % 66;
+            const int gy = y0 + yh - 1, gx = xh - 1;
+            // UNCONDITIONAL load from a clamped address, then a select: a load under a lane-dependent condition makes hipcc branch
+            // around it and wait s_waitcnt vmcnt(0) right behind it -- every element a serial memory round trip that also waits
+            // for all outstanding stores (the round-1 kernel did exactly that: 3.6 TB/s of output with the arithmetic removed)
+            const int cy = gy < 0 ? 0 : (gy > 95 ? 95 : gy), cx = gx < 0 ? 0 : (gx > 63 ? 63 : gx);
+            const float v = load_elem<TIN>(x + (size_t(img) * 96 + cy) * 64 + cx);
+            pre[k] = (p < NP && gy >= 0 && gy < 96 && gx >= 0 && gx < 64) ? v : 0.f;
+        }
+    };
+    auto patch_write = [&]() {
+        _Pragma("unroll") for (int k = 0; k < NL; ++k) {
+            const int p = t + 256 * k;
+            if (p < NP) sX[(p / 66) * PITCH + p % 66] = f2bf(pre[k]);
+        }
+    };
+    // The two barriers of a tile protect LDS only. __syncthreads() would also wait for every outstanding global STORE
+    // (s_waitcnt vmcnt(0): ~3-4 us under a full write load) twice per tile -- the round-1 kernel ran at 3.6 TB/s of output for that
+    // reason alone (stores only, no arithmetic: 0.556 ms; a plain fill of the same 2 GB: 0.29 ms). Raw barrier + LDS counter only.
+    auto lds_barrier = [&]() {
+#if MLA_CONV1_RAW_BARRIER
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#else
+        __syncthreads();
+#endif
+    };
+    int tile = blockIdx.x;
+    if (tile < n_tiles) patch_load(tile);
+    char* stage = sOut + wave * 32 * ROW;
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int img = tile / TPC, y0 = (tile % TPC) * TR;
+        patch_write();
+        lds_barrier();
+        if (tile + int(gridDim.x) < n_tiles) patch_load(tile + int(gridDim.x));
+        _Pragma("unroll") for (int rr = 0; rr < TR / 8; ++rr) {
+            const int prow = wave * (TR / 8) + rr;                                  // pooled row of the tile owned by this wave
+            // B operand: patch rows 2h, 2h+1 of its pixel (local input rows 2 prow + 2h, + 1), columns 2 px .. 2 px + 3 of sX
+            const uint32_t* r0 = reinterpret_cast<const uint32_t*>(sX + (2 * prow + 2 * h) * PITCH) + px;       // 2 px bf16 = px dwords
+            const uint32_t* r1 = reinterpret_cast<const uint32_t*>(sX + (2 * prow + 2 * h + 1) * PITCH) + px;
+            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, u32x4{r0[0], r0[1], r1[0], r1[1]});
+            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {
+                f32x16 m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][mt], bfrag, binit[mt], 0, 0, 0);
+                _Pragma("unroll") for (int pos = 1; pos < 4; ++pos) {
+                    const f32x16 a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[pos][mt], bfrag, binit[mt], 0, 0, 0);
+                    _Pragma("unroll") for (int reg = 0; reg < 16; ++reg) m[reg] = fmaxf(m[reg], a[reg]);
+                }
+                uint32_t pk[8];
+                _Pragma("unroll") for (int e = 0; e < 8; ++e) pk[e] = pack_bf16x2(fmaxf(m[2 * e], 0.f), fmaxf(m[2 * e + 1], 0.f));
+                char* dst = stage + px * ROW + (mt * 32 + 16 * h) * 2;              // 16 consecutive channels of pixel px
+                *reinterpret_cast<u32x4*>(dst) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                *reinterpret_cast<u32x4*>(dst + 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the stage rows belong to this wave only:
+            __builtin_amdgcn_wave_barrier();                            // LDS operations of one wave execute in order
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            char* gdst = reinterpret_cast<char*>(out + ((size_t(img) * 48 + y0 / 2 + prow) * 32) * 64);
+            _Pragma("unroll") for (int it = 0; it < 4; ++it) {                      // 32 pixels x 128 B = 4 KiB contiguous per wave
+                const int piece = it * 64 + lane, p = piece >> 3, c = piece & 7;
+                *reinterpret_cast<u32x4*>(gdst + size_t(piece) * 16) = *reinterpret_cast<const u32x4*>(stage + p * ROW + c * 16);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the reads above precede the next row's stage writes
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        lds_barrier();                                              // every wave is done with sX before the next patch lands
     }
 }
 
@@ -898,6 +1039,14 @@ extern "C" int mla_vggish_conv1(const void* x, int x_dtype, int64_t n, const flo
         hipLaunchKernelGGL((conv1_kernel<float, float, true>), g, b, 0, s, static_cast<const float*>(x), w, bias, static_cast<float*>(out), n_pix);
     else if (x_dtype == MLA_F32 && dtype == MLA_F32)
         hipLaunchKernelGGL((conv1_kernel<float, float>), g, b, 0, s, static_cast<const float*>(x), w, bias, static_cast<float*>(out), n_pix);
+    else if (dtype == MLA_BF16 && !MLA_CONV1_GATHER) {
+        const int64_t tiles = n * (96 / MLA_CONV1_ROWS), slots = int64_t(cus1) * MLA_CONV1_WAVES;
+        const dim3 gp{unsigned(tiles < slots ? tiles : slots)};
+        if (x_dtype == MLA_F32)
+            hipLaunchKernelGGL((conv1_patch_kernel<float>), gp, b, 0, s, static_cast<const float*>(x), w, bias, static_cast<bf16_t*>(out), n_pix);
+        else
+            hipLaunchKernelGGL((conv1_patch_kernel<bf16_t>), gp, b, 0, s, static_cast<const bf16_t*>(x), w, bias, static_cast<bf16_t*>(out), n_pix);
+    }
     else if (x_dtype == MLA_F32)
         hipLaunchKernelGGL((conv1_kernel<float, bf16_t>), g, b, 0, s, static_cast<const float*>(x), w, bias, static_cast<bf16_t*>(out), n_pix);
     else if (dtype == MLA_F32)
