@@ -65,9 +65,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
     _Pragma("unroll") for (int i = 0; i < kMS; ++i)
         _Pragma("unroll") for (int j = 0; j < NS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    constexpr uint32_t ESZ = sizeof(T);
+    const int a_rows = M - m0 < kBM ? M - m0 : kBM, w_rows = N - n0 < BN ? N - n0 : BN;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(A) + size_t(m0) * lda, 0,
+                                                                          uint32_t(a_rows) * uint32_t(lda) * ESZ, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(W) + size_t(n0) * ldw, 0,
+                                                                          uint32_t(w_rows) * uint32_t(ldw) * ESZ, 0x00020000);
     u32x4 areg[AP], breg[NS];
     // seg > 0 ("bf16x3", see conv.hip): W holds [w_hi | w_lo | w_hi] per segment of `seg` K-chunks and A [a_hi | a_lo];
     // weight stage s = 3 seg b + r pairs with activation stage 2 seg b + (r < seg ? r : r - seg). K counts W columns.
+    // register-staged path (K tails, 32-bit descriptor overflow): loads through buffer descriptors whose range check returns zeros
+    // for rows past M / N and columns past K -- no lane-dependent branches around the loads (hipcc would wait for each one)
     auto gload = [&](int s) {
         int sa = s;
         if (seg) {
@@ -77,14 +85,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
         _Pragma("unroll") for (int p = 0; p < AP; ++p) {
             const int piece = t + kThreads * p, row = piece >> 3, ch = piece & 7;
             const int k = sa * KC + ch * PER;
-            areg[p] = zero16();
-            if (m0 + row < M && s * KC + ch * PER < K) areg[p] = *reinterpret_cast<const u32x4*>(A + size_t(m0 + row) * lda + k);
+            const bool ok = m0 + row < M && s * KC + ch * PER < K;
+            areg[p] = __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? int((uint32_t(row) * uint32_t(lda) + k) * sizeof(T)) : int(0x7fffff00), 0, 0);
         }
         _Pragma("unroll") for (int p = 0; p < NS; ++p) {
             const int piece = t + kThreads * p, n = piece >> 3, ch = piece & 7;
             const int k = s * KC + ch * PER;
-            breg[p] = zero16();
-            if (n0 + n < N && k < K) breg[p] = *reinterpret_cast<const u32x4*>(W + size_t(n0 + n) * ldw + k);
+            const bool ok = n0 + n < N && k < K;
+            breg[p] = __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? int((uint32_t(n) * uint32_t(ldw) + k) * sizeof(T)) : int(0x7fffff00), 0, 0);
         }
     };
     auto lwrite = [&](int buf) {
@@ -98,12 +106,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
         }
     };
 
-    constexpr uint32_t ESZ = sizeof(T);
-    const int a_rows = M - m0 < kBM ? M - m0 : kBM, w_rows = N - n0 < BN ? N - n0 : BN;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(A) + size_t(m0) * lda, 0,
-                                                                          uint32_t(a_rows) * uint32_t(lda) * ESZ, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(W) + size_t(n0) * ldw, 0,
-                                                                          uint32_t(w_rows) * uint32_t(ldw) * ESZ, 0x00020000);
     auto dma = [&](int s, int buf) {
         int sa = s;
         if (seg) {
@@ -291,8 +293,9 @@ int launch(const void* a, int64_t lda, const void* w, int64_t ldw, const float* 
     constexpr int lds = 2 * (kBM + BN) * kRowBytes;
     // LDS-DMA staging when no K tail needs zero filling and the descriptors' 32-bit byte ranges suffice
     constexpr int KCE = mma::Elem<T>::kPerRow;
-    const bool use_dma = K % KCE == 0 && uint64_t(kBM) * uint64_t(lda) * sizeof(T) < (1ull << 31) &&
-                         uint64_t(BN) * uint64_t(ldw) * sizeof(T) < (1ull << 31);
+    MLA_REQUIRE(uint64_t(kBM) * uint64_t(lda) * sizeof(T) < (1ull << 31) && uint64_t(BN) * uint64_t(ldw) * sizeof(T) < (1ull << 31), MLA_E_SHAPE,
+                "GEMM row pitch too large for 32-bit buffer offsets (lda %lld, ldw %lld)", (long long)lda, (long long)ldw);
+    const bool use_dma = K % KCE == 0;
     auto kern = use_dma ? gemm_kernel<T, TO, MS, NS, RELU, true> : gemm_kernel<T, TO, MS, NS, RELU, false>;
     MLA_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const dim3 grid{unsigned((M + kBM - 1) / kBM), unsigned((N + BN - 1) / BN), unsigned(splits)};
