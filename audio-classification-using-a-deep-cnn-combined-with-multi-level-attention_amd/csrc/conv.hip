@@ -39,9 +39,18 @@ constexpr int kThreads = 512, kWavesN = 4, kMS = 6;
 #ifndef MLA_CONV_STAMPS
 #define MLA_CONV_STAMPS 0
 #endif
+#ifndef MLA_STAMP_TAP
+#define MLA_STAMP_TAP 4
+#define MLA_STAMP_CHUNK 5
+#endif
 #if MLA_CONV_STAMPS
 __device__ unsigned long long g_conv_stamps[8][2][8];
 #define MLA_STAMP(k) do { if (stamp_on) stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#if MLA_CONV_STAMPS == 2
+#undef MLA_STAMP
+#define MLA_STAMP(k) do { } while (0)
+#define MLA_STAMP2(k) do { if (stamp_on) stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #else
 #define MLA_STAMP(k) do { } while (0)
 #endif
@@ -367,8 +376,8 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                         _Pragma("unroll") for (int j = 0; j < C::NS; ++j) mma_step<T>(af[i], bf[j], acc[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
                 };
-#if MLA_CONV_STAMPS
-                const bool stamp_on = tap == 4 && chunk_counter == 5 && (wave == 0 || wave == 4) && blockIdx.x < 8 && blockIdx.y == 0;
+#if MLA_CONV_STAMPS == 1
+                const bool stamp_on = tap == MLA_STAMP_TAP && chunk_counter == MLA_STAMP_CHUNK && (wave == 0 || wave == 4) && blockIdx.x < 8 && blockIdx.y == 0;
 #endif
                 if constexpr (!LATE) {
                     MLA_STAMP(0);
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                     rd(0);
                     if (MLA_CONV_DMA_LATE) issue_dma();
                     MLA_STAMP(1);
-#if MLA_CONV_STAMPS
+#if MLA_CONV_STAMPS == 1
                     if (stamp_on) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
                     MLA_STAMP(2);
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                     __builtin_amdgcn_s_setprio(0);             // ... its second burst yields to it
 #endif
                     rd(1);
-#if MLA_CONV_STAMPS
+#if MLA_CONV_STAMPS == 1
                     if (stamp_on) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
                     MLA_STAMP(4);
@@ -408,7 +417,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                     __builtin_amdgcn_s_setprio(1);
 #endif
                     rd(0);
-#if MLA_CONV_STAMPS
+#if MLA_CONV_STAMPS == 1
                     if (stamp_on) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
                     MLA_STAMP(2);
@@ -442,12 +451,19 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
             }
         }
 
+#if MLA_CONV_STAMPS == 2
+        const bool stamp_on = chunk_counter == MLA_STAMP_CHUNK && (wave == 0 || wave == 4) && blockIdx.x < 8 && blockIdx.y == 0;
+        MLA_STAMP2(0);
+#endif
         if constexpr (LATE) {                      // the last tap's second k-step
             __builtin_amdgcn_sched_barrier(0);
             _Pragma("unroll") for (int i = 0; i < kMS; ++i)
                 _Pragma("unroll") for (int j = 0; j < C::NS; ++j) mma_step<T>(af[i], bf[j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
+#if MLA_CONV_STAMPS == 2
+        MLA_STAMP2(1);
+#endif
         // epilogue: ReLU (+ lane-local 2x2 max-pool; max commutes with the monotone ReLU; the bias is already in the
         // accumulators); one vector store per pixel.
         {
@@ -497,6 +513,9 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                 }
             }
         }
+#if MLA_CONV_STAMPS == 2
+        MLA_STAMP2(2);
+#endif
         if (!has_next) break;
         tile = next_tile;
         img0 = (tile / C::TILES_Y) * C::IMGS;
