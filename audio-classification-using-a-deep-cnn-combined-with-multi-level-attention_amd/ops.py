@@ -415,7 +415,9 @@ def axpy(a, x, y):
 
 
 def check_labels(labels, K):
-    """nn.CrossEntropyLoss raises on a target outside [0, K) (train.py:372 has no ignore_index). Host tensors are checked
+    """nn.CrossEntropyLoss raises on a target outside [0, K) (train.py:372 keeps the default ignore_index=-100, a value the
+    reference's dataset never produces -- labels are class indices, dataset.py:60-75 -- and which is refused here like any other
+    negative label rather than silently dropped from the mean). Host tensors are checked
     here before the upload (no device sync); for device tensors the kernel refuses to index with such a label and reports
     it through `n_correct < 0` + a NaN loss, which `raise_on_bad_labels` turns into the same exception."""
     if not labels.is_cuda and labels.numel():
