@@ -31,7 +31,7 @@ namespace {
 
 using namespace mma;
 
-constexpr int kThreads = 512, kWavesN = 4, kMS = 6;
+constexpr int kThreads = 512, kWaves = 8, kMS = 6;
 
 // Diagnostic build only (-DMLA_CONV_STAMPS=1, scripts/build_variant.py): s_memtime stamps of ONE tap (tap 4 of a workgroup's
 // second channel chunk) of waves 0 and 4 of the first 8 workgroups, written to a buffer nothing else reads; read back through
@@ -73,6 +73,15 @@ __device__ unsigned long long g_conv_stamps[8][2][8];
 #ifndef MLA_CONV1_GATHER
 #define MLA_CONV1_GATHER 0          // 1: bf16 conv1 through the round-1 gather kernel (A/B builds)
 #endif
+#ifndef MLA_CONV_TALL
+#define MLA_CONV_TALL 1              // bf16 conv2..conv4 on 384 x 128 tiles (0: A/B builds on the 192 x 256 / 192 x 128 tiles)
+#endif
+#ifndef MLA_CONV_PATCH_SPREAD
+#define MLA_CONV_PATCH_SPREAD 1
+#endif
+#ifndef MLA_CONV_DMA_DIV
+#define MLA_CONV_DMA_DIV 1
+#endif
 #ifndef MLA_CONV_DMA_LATE
 #define MLA_CONV_DMA_LATE 1
 #endif
@@ -84,8 +93,12 @@ __device__ unsigned long long g_conv_stamps[8][2][8];
 // relative). Activations hold [hi(C) | lo(C)] per pixel, repacked weights [hi | lo | hi] per 64-channel chunk and tap, and
 // the K loop runs the three products a_hi w_hi + a_hi w_lo + a_lo w_hi (bf16 products are exact in the f32 accumulator;
 // the dropped a_lo w_lo is 2^-18 relative): f32-grade results at a third of the bf16 MFMA rate.
-template <typename T, int CIN_, int COUT_, int H_, int W_, bool POOL_, int NS_, bool ACT_ = true, bool SPLIT_ = false>
+// WM: waves along M. 2 (x 4 along N): tile 192 pixels x 64 NS channels. 4 (x 2 along N, "tall"): 384 pixels x 32 NS channels -- the same
+// 6 x NS accumulator tiles per wave, but a weight slice (the operand that is re-fetched for every tap) is half as large per FLOP:
+// L2 -> LDS traffic per tap 22.7 instead of 35.2 KB (conv4), which this power-limited kernel returns as clock (section 3.3 of DESIGN.md).
+template <typename T, int CIN_, int COUT_, int H_, int W_, bool POOL_, int NS_, bool ACT_ = true, bool SPLIT_ = false, int WM_ = 2>
 struct Cfg {
+    static constexpr int WM = WM_, WN = kWaves / WM_;
     using elem = T;
     static constexpr int CIN = CIN_, COUT = COUT_, H = H_, W = W_, NS = NS_;
     static constexpr bool POOL = POOL_;
@@ -98,9 +111,9 @@ struct Cfg {
     static constexpr int SEGW = W >= 16 ? 16 : 8;          // pixels of one image row per m-subtile
     static constexpr int SEGS = W / SEGW;                   // subtiles per tile row (2 for W = 32)
     static constexpr int IMGS = 16 / SEGW;                  // images per tile (2 for W = 8)
-    static constexpr int TH = 12 / SEGS;                    // tile rows: 12 m-subtiles per tile
+    static constexpr int TH = kMS * WM / SEGS;              // tile rows: 6 m-subtiles per wave along M
     static constexpr int PW = W + 2, PH = TH + 2;           // patch with halo
-    static constexpr int BN = kWavesN * NS * 16;
+    static constexpr int BN = WN * NS * 16;
     static constexpr int KC = Elem<T>::kPerRow;             // channels per 128-byte chunk
     static constexpr int A_PIX = IMGS * PH * PW;            // patch pixels (one 128-byte row each)
     static constexpr int A_BYTES = (A_PIX + 7) / 8 * 8 * kRowBytes;   // padded to whole 1 KiB LDS-DMA pieces
@@ -112,6 +125,9 @@ struct Cfg {
     static constexpr bool A_DMA = PERSIST;                  // input patches by LDS-DMA into two alternating buffers (else: one
                                                             // buffer, register-staged -- the two-workgroups-per-CU configurations)
     static constexpr int A_BUFS = A_DMA ? 2 : 1;
+    // the next patch's DMA pieces one per wave and tap instead of all in tap 2: measured per shape (same-device A/B) +3.2 % on the
+    // tall conv4, -1 ... -2 % on conv3 / conv5 (register allocation shifts), neutral elsewhere
+    static constexpr bool PATCH_SPREAD = MLA_CONV_PATCH_SPREAD && WM_ == 4 && CIN_ >= 256;
     // Stagger (one workgroup per CU = two waves per SIMD that would otherwise run in lockstep): waves 4-7 -- the SIMD partners
     // of waves 0-3 -- run half a tap behind. Their k-step-1 fragments are READ before the barrier that ends a tap (the slice is
     // still valid there) and MULTIPLIED after it, so right after every barrier one wave of each SIMD has a full burst of MFMAs
@@ -121,6 +137,7 @@ struct Cfg {
     static constexpr int LDS_BYTES = A_BUFS * A_BYTES + 2 * B_BYTES;
     static constexpr int HO = POOL ? H / 2 : H, WO = POOL ? W / 2 : W;
     static_assert(W == 32 || W == 16 || W == 8, "tile mapping covers the VGGish widths");
+    static_assert(WM == 2 || (WM == 4 && W >= 16), "tall tiles: W = 16 (whole image) or W = 32 (12 rows); four W = 8 images with halo do not fit LDS twice");
     static_assert(H % TH == 0 && CIN % KC == 0 && COUT % BN == 0, "shape must tile exactly");
     static_assert((PW * kRowBytes) % 256 == 0, "row pitch must keep the bank swizzle invariant");
     static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
@@ -182,7 +199,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
     char* sA = smem;
     char* sB = smem + C::A_BUFS * C::A_BYTES;
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 2, wn = wave & 3;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / C::WN, wn = wave % C::WN;
     const int r = lane & 15, q = lane >> 4;
     // Persistent workgroup: tiles blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is a multiple of
     // TILES_Y, so the tile row `ty` -- and with it every per-lane global offset -- is fixed for life).
@@ -194,8 +211,10 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
 
     // this lane's pixel inside the tile (A-operand row r of every m-subtile of the wave)
     const int l_img = C::SEGW == 8 ? (r >> 3) : 0;
-    const int l_x = C::SEGW == 8 ? (r & 7) : ((C::SEGS == 2 ? wm * 16 : 0) + r);
-    const int l_y0 = C::SEGS == 2 ? 0 : kMS * wm;
+    // the wave's 6 subtiles: rows l_y0 .. l_y0 + 5 of the tile, x half wxh of a 32-wide row
+    const int wxh = C::SEGS == 2 ? (wm & 1) : 0, wy = C::SEGS == 2 ? (wm >> 1) : wm;
+    const int l_x = C::SEGW == 8 ? (r & 7) : (wxh * 16 + r);
+    const int l_y0 = kMS * wy;
     int abase[3];
     _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {
         const int xh = l_x + kx;
@@ -265,7 +284,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
     // LDS row j*16 + r of a wave's NS*16-row block holds output channel r*NS + j of that block: the NS accumulators
     // of a lane are then NS consecutive channels and leave as one vector store per pixel.
     auto b_dma = [&](int c0, int tap, int buf_off) {
-        _Pragma("unroll") for (int p = 0; p < C::NS; ++p) {
+        _Pragma("unroll") for (int p = 0; p < C::BN / 64 / MLA_CONV_DMA_DIV; ++p) {  // DIV > 1: timing experiment only (wrong results)
             const int row = 8 * (wave + 8 * p) + (lane >> 3), slot = lane & 7;
             const int chunk = slot ^ (((row >> 1) & 3) << 1);                    // inverse of tile_off's swizzle (an involution)
             const int n = (row & ~(C::NS * 16 - 1)) + (row & 15) * C::NS + ((row >> 4) & (C::NS - 1));
@@ -278,22 +297,25 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
     // source side. Out-of-image halo pixels (and images past the batch) carry an out-of-range offset: the range check
     // DROPS those lanes, so the halo rows of both patch buffers are zeroed once, below, and never written again -- they
     // are the same LDS rows for every tile of this workgroup (its tile row is fixed, the x halo always is).
-    auto a_dma = [&](int c0, int abuf) {
-        constexpr int A_INSTRS = (C::A_PIX + 7) / 8;
-        _Pragma("unroll") for (int p = 0; p < (A_INSTRS + 7) / 8; ++p) {
-            const int wi = wave + 8 * p;                           // wave-uniform piece index
-            if (wi < A_INSTRS) {
-                const int pix = 8 * wi + (lane >> 3), slot = lane & 7;
-                const int xh = pix % C::PW, rest = pix / C::PW;
-                const int yh = rest % C::PH, im = rest / C::PH;
-                const int gy = y_tile + yh - 1, gx = xh - 1;
-                const bool ok = pix < C::A_PIX && gy >= 0 && gy < C::H && gx >= 0 && gx < C::W;
-                const int chunk = slot ^ a_swizzle<C>(xh, im);
-                const int voff = ok ? int((((im * C::H + gy) * C::W + gx) * C::CIN_A + chunk * PER) * ESZ) : int(0x7fffff00);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(sA + abuf * C::A_BYTES + wi * 8 * kRowBytes),
-                                                         16, voff, int(c0 * ESZ), 0, 0);
-            }
+    constexpr int A_INSTRS = (C::A_PIX + 7) / 8;          // 1 KiB DMA pieces per patch
+    constexpr int A_ROUNDS = (A_INSTRS + 7) / 8;          // one piece per wave and round
+    static_assert(A_ROUNDS <= 9, "a patch is staged within the nine taps of the previous chunk");
+    auto a_dma_round = [&](int c0, int abuf, int p) {
+        const int wi = wave + 8 * p;                           // wave-uniform piece index
+        if (wi < A_INSTRS) {
+            const int pix = 8 * wi + (lane >> 3), slot = lane & 7;
+            const int xh = pix % C::PW, rest = pix / C::PW;
+            const int yh = rest % C::PH, im = rest / C::PH;
+            const int gy = y_tile + yh - 1, gx = xh - 1;
+            const bool ok = pix < C::A_PIX && gy >= 0 && gy < C::H && gx >= 0 && gx < C::W;
+            const int chunk = slot ^ a_swizzle<C>(xh, im);
+            const int voff = ok ? int((((im * C::H + gy) * C::W + gx) * C::CIN_A + chunk * PER) * ESZ) : int(0x7fffff00);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(sA + abuf * C::A_BYTES + wi * 8 * kRowBytes),
+                                                     16, voff, int(c0 * ESZ), 0, 0);
         }
+    };
+    auto a_dma = [&](int c0, int abuf) {
+        _Pragma("unroll") for (int p = 0; p < A_ROUNDS; ++p) a_dma_round(c0, abuf, p);
     };
 
     // prologue: first patch and first weight slice
@@ -349,7 +371,14 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                     if (tap < 8) b_dma(c0, tap + 1, cur ^ C::B_BYTES);
                     else if (more) b_dma(last_chunk ? 0 : c0 + C::KC, 0, cur ^ C::B_BYTES);
                     if constexpr (C::A_DMA) {
-                        if (tap == 2 && new_patch) {   // next chunk's / tile's patch into the other patch buffer (idle since the previous chunk)
+                        // next chunk's / tile's patch into the other patch buffer (idle since the previous chunk), one piece per wave
+                        // and tap (MLA_CONV_PATCH_SPREAD) so that no tap carries the whole patch's DMA issue
+                        if constexpr (C::PATCH_SPREAD) {
+                          if (tap < A_ROUNDS && new_patch) {
+                            if (tap == 0 && last_chunk) a_rsrc = patch_rsrc((next_tile / C::TILES_Y) * C::IMGS);
+                            a_dma_round(last_chunk ? 0 : a_chan(c + 1), abuf ^ 1, tap);
+                          }
+                        } else if (tap == 2 && new_patch) {
                             if (last_chunk) a_rsrc = patch_rsrc((next_tile / C::TILES_Y) * C::IMGS);
                             a_dma(last_chunk ? 0 : a_chan(c + 1), abuf ^ 1);
                         }
@@ -478,7 +507,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                             _Pragma("unroll") for (int j = 0; j < C::NS; ++j) v[j] = fmaxf(acc[i][j][e], 0.f);
                             const int rr = 4 * q + e;
                             const int img = img0 + (C::SEGW == 8 ? (rr >> 3) : 0);
-                            const int x = C::SEGW == 8 ? (rr & 7) : ((C::SEGS == 2 ? wm * 16 : 0) + rr);
+                            const int x = C::SEGW == 8 ? (rr & 7) : ((wxh * 16) + rr);
                             if (img < n_img) store_vec<T, C::NS>(prepool + ((size_t(img) * C::H + y) * C::W + x) * C::COUT + nb, v);
                         }
                     }
@@ -492,7 +521,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                     }
                     const int yo = (y_tile + l_y0 + 2 * ip) >> 1;
                     const int img = img0 + (C::SEGW == 8 ? (q >> 1) : 0);
-                    const int xo = C::SEGW == 8 ? 2 * (q & 1) : (((C::SEGS == 2 ? wm * 16 : 0) + 4 * q) >> 1);
+                    const int xo = C::SEGW == 8 ? 2 * (q & 1) : (((wxh * 16) + 4 * q) >> 1);
                     if (img < n_img) {
                         T* o = out + ((size_t(img) * C::HO + yo) * C::WO + xo) * C::COUT_MEM + nb;
                         store_px<C>(o, p0);
@@ -507,7 +536,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                         _Pragma("unroll") for (int j = 0; j < C::NS; ++j) v[j] = C::ACT ? fmaxf(acc[i][j][e], 0.f) : acc[i][j][e];
                         const int rr = 4 * q + e;
                         const int img = img0 + (C::SEGW == 8 ? (rr >> 3) : 0);
-                        const int x = C::SEGW == 8 ? (rr & 7) : ((C::SEGS == 2 ? wm * 16 : 0) + rr);
+                        const int x = C::SEGW == 8 ? (rr & 7) : ((wxh * 16) + rr);
                         if (img < n_img) store_px<C>(out + ((size_t(img) * C::H + y) * C::W + x) * C::COUT_MEM + nb, v);
                     }
                 }
@@ -850,6 +879,13 @@ int launch_conv(const void* in, const void* w, const float* bias, void* out, int
 
 template <typename T>
 int conv_layer(int layer, const void* in, const void* w, const float* bias, void* out, int64_t n, hipStream_t s) {
+    if constexpr (sizeof(T) == 2 && MLA_CONV_TALL) {     // bf16, W >= 16: tall tiles (384 pixels x 128 channels)
+        switch (layer) {
+            case 2: return launch_conv<Cfg<T, 64, 128, 48, 32, true, 4, true, false, 4>>(in, w, bias, out, n, s);
+            case 3: return launch_conv<Cfg<T, 128, 256, 24, 16, false, 4, true, false, 4>>(in, w, bias, out, n, s);
+            case 4: return launch_conv<Cfg<T, 256, 256, 24, 16, true, 4, true, false, 4>>(in, w, bias, out, n, s);
+        }
+    }
     switch (layer) {                                     //        Cin Cout  H   W  pool NS
         case 2: return launch_conv<Cfg<T, 64, 128, 48, 32, true, 2>>(in, w, bias, out, n, s);
         case 3: return launch_conv<Cfg<T, 128, 256, 24, 16, false, 4>>(in, w, bias, out, n, s);
@@ -891,19 +927,28 @@ int conv_generic(const void* in, const void* w, const float* bias, void* out, in
 #define MLA_CONV_CASE(CI, CO, HH, WW, PO, NS_, AC)                                                             \
     if (cin == CI && cout == CO && H == HH && W == WW && pool == PO && act == AC)                              \
         return launch_conv<Cfg<T, CI, CO, HH, WW, PO, NS_, AC>>(in, w, bias, out, n, s, prepool);
-    MLA_CONV_CASE(64, 128, 48, 32, true, 2, true)
-    MLA_CONV_CASE(128, 256, 24, 16, false, 4, true)
-    MLA_CONV_CASE(256, 256, 24, 16, true, 4, true)
+    // W >= 16, Cout >= 128: bf16 runs the tall tile (384 pixels x 128 channels, NS = 4), f32 the wide one with NS_ as given
+#define MLA_CONV_CASE_TALL(CI, CO, HH, WW, PO, NS_, AC)                                                        \
+    if (cin == CI && cout == CO && H == HH && W == WW && pool == PO && act == AC) {                            \
+        if constexpr (sizeof(T) == 2 && MLA_CONV_TALL)                                                         \
+            return launch_conv<Cfg<T, CI, CO, HH, WW, PO, 4, AC, false, 4>>(in, w, bias, out, n, s, prepool);  \
+        else                                                                                                   \
+            return launch_conv<Cfg<T, CI, CO, HH, WW, PO, NS_, AC>>(in, w, bias, out, n, s, prepool);          \
+    }
+    MLA_CONV_CASE_TALL(64, 128, 48, 32, true, 2, true)
+    MLA_CONV_CASE_TALL(128, 256, 24, 16, false, 4, true)
+    MLA_CONV_CASE_TALL(256, 256, 24, 16, true, 4, true)
     MLA_CONV_CASE(256, 512, 12, 8, false, 4, true)
     MLA_CONV_CASE(512, 512, 12, 8, true, 4, true)
-    MLA_CONV_CASE(64, 128, 48, 32, false, 2, true)        // training forward: pre-pool activations kept
-    MLA_CONV_CASE(256, 256, 24, 16, false, 4, true)
+    MLA_CONV_CASE_TALL(64, 128, 48, 32, false, 2, true)   // training forward: pre-pool activations kept
+    MLA_CONV_CASE_TALL(256, 256, 24, 16, false, 4, true)
     MLA_CONV_CASE(512, 512, 12, 8, false, 4, true)
     MLA_CONV_CASE(512, 512, 12, 8, false, 4, false)       // dgrad conv6
     MLA_CONV_CASE(512, 256, 12, 8, false, 4, false)       // dgrad conv5
-    MLA_CONV_CASE(256, 256, 24, 16, false, 4, false)      // dgrad conv4
-    MLA_CONV_CASE(256, 128, 24, 16, false, 2, false)      // dgrad conv3
+    MLA_CONV_CASE_TALL(256, 256, 24, 16, false, 4, false) // dgrad conv4
+    MLA_CONV_CASE_TALL(256, 128, 24, 16, false, 2, false) // dgrad conv3
     MLA_CONV_CASE(128, 64, 48, 32, false, 1, false)       // dgrad conv2
+#undef MLA_CONV_CASE_TALL
 #undef MLA_CONV_CASE
     return mla::fail(MLA_E_SHAPE, "conv3x3 %dx%d %d->%d pool=%d act=%d is not compiled", H, W, cin, cout, int(pool), int(act));
 }

@@ -503,18 +503,28 @@ def infer_mode(args, world, rank, device, ops):
                                   "traffic": t_fe["bytes_per_clip"] * clips_per_step if t_fe else None},
             "kernel_ms": {k: round(v * 1e3, 4) for k, v in sorted(avg.items())},
         }
+        def leg(name, fn):
+            """The additional legs of the N = 1 line never cost the headline line: a failure is reported in place."""
+            try:
+                result[name] = fn()
+            except Exception as e:                                   # noqa: BLE001 -- reported, not hidden
+                result[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                print("bench.py: leg %s failed: %r" % (name, e), file=sys.stderr, flush=True)
+
         if world == 1 and args.precision == "bf16" and not args.no_parity_mode:
-            result["parity_mode"] = parity_mode_leg(ens, pcm, clips_per_step, ops)
+            leg("parity_mode", lambda: parity_mode_leg(ens, pcm, clips_per_step, ops))
         if world == 1 and not args.no_h2d:
-            result["h2d"] = h2d_leg(pcm, elapsed / args.steps, clips_per_step, ens=ens)
+            leg("h2d", lambda: h2d_leg(pcm, elapsed / args.steps, clips_per_step, ens=ens))
         if world == 1 and not args.no_small_batch:
-            result["small_batch"] = small_batch_leg(ens, rank, device)
+            leg("small_batch", lambda: small_batch_leg(ens, rank, device))
         if world == 1 and not args.no_cpu_baseline:
-            with torch.no_grad():
-                result["cpu_baseline"] = cpu_baseline(sd, ens, device)
+            def cpu_leg():
+                with torch.no_grad():
+                    return cpu_baseline(sd, ens, device)
+            leg("cpu_baseline", cpu_leg)
         # north star: "logits within 1e-4 rel of the CPU reference" -- the throughput of the fastest arithmetic mode whose
         # MEASURED deviation from the oracle meets it, stated at top level beside `value` (which is BASELINE config 3's bf16)
-        if "cpu_baseline" in result and "parity_mode" in result:
+        if "parity_max_rel_bf16" in result.get("cpu_baseline", {}) and "bf16x3" in result.get("parity_mode", {}):
             cands = [("bf16", result["value"], result["roofline_conv_stack"]["frac"], result["roofline_conv_stack"]["frac"])]
             for m in ("bf16x3", "f32"):
                 pm = result["parity_mode"][m]
@@ -528,7 +538,7 @@ def infer_mode(args, world, rank, device, ops):
         if world == 1 and not args.no_train_leg:
             del ens, pcm
             torch.cuda.empty_cache()
-            result["train_step"] = train_leg(device)
+            leg("train_step", lambda: train_leg(device))
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
