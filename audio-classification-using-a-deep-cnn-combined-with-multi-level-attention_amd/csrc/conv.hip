@@ -74,7 +74,7 @@ __device__ unsigned long long g_conv_stamps[8][2][8];
 #define MLA_CONV1_GATHER 0          // 1: bf16 conv1 through the round-1 gather kernel (A/B builds)
 #endif
 #ifndef MLA_CONV_TALL
-#define MLA_CONV_TALL 1              // bf16 conv2..conv4 on 384 x 128 tiles (0: A/B builds on the 192 x 256 / 192 x 128 tiles)
+#define MLA_CONV_TALL 2              // bf16 layers on 384 x 128 tiles: 1 = conv2..conv4 (W >= 16), 2 = conv5 / conv6 (W = 8) too; 0: A/B builds on the 192-pixel tiles
 #endif
 #ifndef MLA_CONV_PATCH_SPREAD
 #define MLA_CONV_PATCH_SPREAD 1
@@ -110,12 +110,16 @@ struct Cfg {
     static_assert(!SPLIT || (sizeof(T) == 2 && ACT_), "the split mode is a bf16 forward mode");
     static constexpr int SEGW = W >= 16 ? 16 : 8;          // pixels of one image row per m-subtile
     static constexpr int SEGS = W / SEGW;                   // subtiles per tile row (2 for W = 32)
-    static constexpr int IMGS = 16 / SEGW;                  // images per tile (2 for W = 8)
-    static constexpr int TH = kMS * WM / SEGS;              // tile rows: 6 m-subtiles per wave along M
-    static constexpr int PW = W + 2, PH = TH + 2;           // patch with halo
+    static constexpr int IMGS = SEGW == 8 ? WM : 1;         // images per tile (W = 8: one image pair per two waves along M)
+    static constexpr int TH = SEGW == 8 ? 12 : kMS * WM / SEGS;   // tile rows: 6 m-subtiles per wave along M
+    // patch with halo; PW is the row PITCH. Four W = 8 images (tall tile) only fit LDS twice at pitch 9: a row's right halo pixel
+    // IS the next row's left one (both are zero), one extra pixel closes the last row. The swizzle depends on the column only and
+    // the images of a subtile are 14 rows = 126 pixels (even) apart, so a read class still sees 8 consecutive columns of one row
+    // parity = 8 distinct bank slots (mma_core.h).
+    static constexpr int PW = (W == 8 && WM == 4) ? 9 : W + 2, PH = TH + 2;
     static constexpr int BN = WN * NS * 16;
     static constexpr int KC = Elem<T>::kPerRow;             // channels per 128-byte chunk
-    static constexpr int A_PIX = IMGS * PH * PW;            // patch pixels (one 128-byte row each)
+    static constexpr int A_PIX = IMGS * PH * PW + (PW & 1); // patch pixels (one 128-byte row each)
     static constexpr int A_BYTES = (A_PIX + 7) / 8 * 8 * kRowBytes;   // padded to whole 1 KiB LDS-DMA pieces
     static constexpr int B_BYTES = BN * kRowBytes;
     static constexpr int TILES_Y = H / TH;
@@ -137,9 +141,9 @@ struct Cfg {
     static constexpr int LDS_BYTES = A_BUFS * A_BYTES + 2 * B_BYTES;
     static constexpr int HO = POOL ? H / 2 : H, WO = POOL ? W / 2 : W;
     static_assert(W == 32 || W == 16 || W == 8, "tile mapping covers the VGGish widths");
-    static_assert(WM == 2 || (WM == 4 && W >= 16), "tall tiles: W = 16 (whole image) or W = 32 (12 rows); four W = 8 images with halo do not fit LDS twice");
+    static_assert(WM == 2 || WM == 4, "waves are laid out 2 x 4 or 4 x 2");
     static_assert(H % TH == 0 && CIN % KC == 0 && COUT % BN == 0, "shape must tile exactly");
-    static_assert((PW * kRowBytes) % 256 == 0, "row pitch must keep the bank swizzle invariant");
+    static_assert((PW * kRowBytes) % 256 == 0 || (W == 8 && (PH * PW) % 2 == 0), "row pitch / image distance must keep the bank swizzle invariant");
     static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
 };
 
@@ -210,9 +214,10 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
     int img0 = (tile / C::TILES_Y) * C::IMGS;
 
     // this lane's pixel inside the tile (A-operand row r of every m-subtile of the wave)
-    const int l_img = C::SEGW == 8 ? (r >> 3) : 0;
+    const int wimg = C::SEGW == 8 ? 2 * (wm >> 1) : 0;      // W = 8: waves 2k, 2k+1 along M share image pair k
     // the wave's 6 subtiles: rows l_y0 .. l_y0 + 5 of the tile, x half wxh of a 32-wide row
-    const int wxh = C::SEGS == 2 ? (wm & 1) : 0, wy = C::SEGS == 2 ? (wm >> 1) : wm;
+    const int wxh = C::SEGS == 2 ? (wm & 1) : 0, wy = C::SEGS == 2 ? (wm >> 1) : (C::SEGW == 8 ? (wm & 1) : wm);
+    const int l_img = C::SEGW == 8 ? wimg + (r >> 3) : 0;
     const int l_x = C::SEGW == 8 ? (r & 7) : (wxh * 16 + r);
     const int l_y0 = kMS * wy;
     int abase[3];
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                             float v[C::NS];
                             _Pragma("unroll") for (int j = 0; j < C::NS; ++j) v[j] = fmaxf(acc[i][j][e], 0.f);
                             const int rr = 4 * q + e;
-                            const int img = img0 + (C::SEGW == 8 ? (rr >> 3) : 0);
+                            const int img = img0 + (C::SEGW == 8 ? wimg + (rr >> 3) : 0);
                             const int x = C::SEGW == 8 ? (rr & 7) : ((wxh * 16) + rr);
                             if (img < n_img) store_vec<T, C::NS>(prepool + ((size_t(img) * C::H + y) * C::W + x) * C::COUT + nb, v);
                         }
@@ -520,7 +525,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                         p1[j] = fmaxf(fmaxf(fmaxf(u.z, u.w), fmaxf(d.z, d.w)), 0.f);
                     }
                     const int yo = (y_tile + l_y0 + 2 * ip) >> 1;
-                    const int img = img0 + (C::SEGW == 8 ? (q >> 1) : 0);
+                    const int img = img0 + (C::SEGW == 8 ? wimg + (q >> 1) : 0);
                     const int xo = C::SEGW == 8 ? 2 * (q & 1) : (((wxh * 16) + 4 * q) >> 1);
                     if (img < n_img) {
                         T* o = out + ((size_t(img) * C::HO + yo) * C::WO + xo) * C::COUT_MEM + nb;
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                         float v[C::NS];
                         _Pragma("unroll") for (int j = 0; j < C::NS; ++j) v[j] = C::ACT ? fmaxf(acc[i][j][e], 0.f) : acc[i][j][e];
                         const int rr = 4 * q + e;
-                        const int img = img0 + (C::SEGW == 8 ? (rr >> 3) : 0);
+                        const int img = img0 + (C::SEGW == 8 ? wimg + (rr >> 3) : 0);
                         const int x = C::SEGW == 8 ? (rr & 7) : ((wxh * 16) + rr);
                         if (img < n_img) store_px<C>(out + ((size_t(img) * C::H + y) * C::W + x) * C::COUT_MEM + nb, v);
                     }
@@ -884,6 +889,10 @@ int conv_layer(int layer, const void* in, const void* w, const float* bias, void
             case 2: return launch_conv<Cfg<T, 64, 128, 48, 32, true, 4, true, false, 4>>(in, w, bias, out, n, s);
             case 3: return launch_conv<Cfg<T, 128, 256, 24, 16, false, 4, true, false, 4>>(in, w, bias, out, n, s);
             case 4: return launch_conv<Cfg<T, 256, 256, 24, 16, true, 4, true, false, 4>>(in, w, bias, out, n, s);
+#if MLA_CONV_TALL >= 2
+            case 5: return launch_conv<Cfg<T, 256, 512, 12, 8, false, 4, true, false, 4>>(in, w, bias, out, n, s);
+            case 6: return launch_conv<Cfg<T, 512, 512, 12, 8, true, 4, true, false, 4>>(in, w, bias, out, n, s);
+#endif
         }
     }
     switch (layer) {                                     //        Cin Cout  H   W  pool NS
@@ -927,7 +936,7 @@ int conv_generic(const void* in, const void* w, const float* bias, void* out, in
 #define MLA_CONV_CASE(CI, CO, HH, WW, PO, NS_, AC)                                                             \
     if (cin == CI && cout == CO && H == HH && W == WW && pool == PO && act == AC)                              \
         return launch_conv<Cfg<T, CI, CO, HH, WW, PO, NS_, AC>>(in, w, bias, out, n, s, prepool);
-    // W >= 16, Cout >= 128: bf16 runs the tall tile (384 pixels x 128 channels, NS = 4), f32 the wide one with NS_ as given
+    // Cout >= 128: bf16 runs the tall tile (384 pixels x 128 channels, NS = 4), f32 the wide one with NS_ as given
 #define MLA_CONV_CASE_TALL(CI, CO, HH, WW, PO, NS_, AC)                                                        \
     if (cin == CI && cout == CO && H == HH && W == WW && pool == PO && act == AC) {                            \
         if constexpr (sizeof(T) == 2 && MLA_CONV_TALL)                                                         \
@@ -935,20 +944,26 @@ int conv_generic(const void* in, const void* w, const float* bias, void* out, in
         else                                                                                                   \
             return launch_conv<Cfg<T, CI, CO, HH, WW, PO, NS_, AC>>(in, w, bias, out, n, s, prepool);          \
     }
+#if MLA_CONV_TALL >= 2
+#define MLA_CONV_CASE_TALL8 MLA_CONV_CASE_TALL
+#else
+#define MLA_CONV_CASE_TALL8 MLA_CONV_CASE
+#endif
     MLA_CONV_CASE_TALL(64, 128, 48, 32, true, 2, true)
     MLA_CONV_CASE_TALL(128, 256, 24, 16, false, 4, true)
     MLA_CONV_CASE_TALL(256, 256, 24, 16, true, 4, true)
-    MLA_CONV_CASE(256, 512, 12, 8, false, 4, true)
-    MLA_CONV_CASE(512, 512, 12, 8, true, 4, true)
+    MLA_CONV_CASE_TALL8(256, 512, 12, 8, false, 4, true)
+    MLA_CONV_CASE_TALL8(512, 512, 12, 8, true, 4, true)
     MLA_CONV_CASE_TALL(64, 128, 48, 32, false, 2, true)   // training forward: pre-pool activations kept
     MLA_CONV_CASE_TALL(256, 256, 24, 16, false, 4, true)
-    MLA_CONV_CASE(512, 512, 12, 8, false, 4, true)
-    MLA_CONV_CASE(512, 512, 12, 8, false, 4, false)       // dgrad conv6
-    MLA_CONV_CASE(512, 256, 12, 8, false, 4, false)       // dgrad conv5
+    MLA_CONV_CASE_TALL8(512, 512, 12, 8, false, 4, true)
+    MLA_CONV_CASE_TALL8(512, 512, 12, 8, false, 4, false)       // dgrad conv6
+    MLA_CONV_CASE_TALL8(512, 256, 12, 8, false, 4, false)       // dgrad conv5
     MLA_CONV_CASE_TALL(256, 256, 24, 16, false, 4, false) // dgrad conv4
     MLA_CONV_CASE_TALL(256, 128, 24, 16, false, 2, false) // dgrad conv3
     MLA_CONV_CASE(128, 64, 48, 32, false, 1, false)       // dgrad conv2
 #undef MLA_CONV_CASE_TALL
+#undef MLA_CONV_CASE_TALL8
 #undef MLA_CONV_CASE
     return mla::fail(MLA_E_SHAPE, "conv3x3 %dx%d %d->%d pool=%d act=%d is not compiled", H, W, cin, cout, int(pool), int(act));
 }
