@@ -79,6 +79,9 @@ __device__ unsigned long long g_conv_stamps[8][2][8];
 #ifndef MLA_CONV_PATCH_SPREAD
 #define MLA_CONV_PATCH_SPREAD 1
 #endif
+#ifndef MLA_CONV_TALL_SPLIT
+#define MLA_CONV_TALL_SPLIT 1
+#endif
 #ifndef MLA_CONV_DMA_DIV
 #define MLA_CONV_DMA_DIV 1
 #endif
@@ -906,6 +909,15 @@ int conv_layer(int layer, const void* in, const void* w, const float* bias, void
 }
 
 int conv_layer_split(int layer, const void* in, const void* w, const float* bias, void* out, int64_t n, hipStream_t s) {
+#if MLA_CONV_TALL_SPLIT
+    switch (layer) {
+        case 2: return launch_conv<Cfg<bf16_t, 64, 128, 48, 32, true, 4, true, true, 4>>(in, w, bias, out, n, s);
+        case 3: return launch_conv<Cfg<bf16_t, 128, 256, 24, 16, false, 4, true, true, 4>>(in, w, bias, out, n, s);
+        case 4: return launch_conv<Cfg<bf16_t, 256, 256, 24, 16, true, 4, true, true, 4>>(in, w, bias, out, n, s);
+        case 5: return launch_conv<Cfg<bf16_t, 256, 512, 12, 8, false, 4, true, true, 4>>(in, w, bias, out, n, s);
+        case 6: return launch_conv<Cfg<bf16_t, 512, 512, 12, 8, true, 4, true, true, 4>>(in, w, bias, out, n, s);
+    }
+#else
     switch (layer) {
         case 2: return launch_conv<Cfg<bf16_t, 64, 128, 48, 32, true, 2, true, true>>(in, w, bias, out, n, s);
         case 3: return launch_conv<Cfg<bf16_t, 128, 256, 24, 16, false, 4, true, true>>(in, w, bias, out, n, s);
@@ -913,6 +925,7 @@ int conv_layer_split(int layer, const void* in, const void* w, const float* bias
         case 5: return launch_conv<Cfg<bf16_t, 256, 512, 12, 8, false, 4, true, true>>(in, w, bias, out, n, s);
         case 6: return launch_conv<Cfg<bf16_t, 512, 512, 12, 8, true, 4, true, true>>(in, w, bias, out, n, s);
     }
+#endif
     return mla::fail(MLA_E_SHAPE, "conv layer %d is not one of VGGish conv2..conv6", layer);
 }
 
