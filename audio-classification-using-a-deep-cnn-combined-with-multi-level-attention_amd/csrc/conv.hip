@@ -13,8 +13,9 @@
 // Roofline: MFMA. Algorithmic work 2 * H*W * Cout * 9*Cin FLOP per frame and layer
 // (SURVEY.md section 8a, row a9): 226.5 / 226.5 / 453.0 / 226.5 / 453.0 MFLOP for conv2..conv4_2.
 //
-// Workgroup = 512 threads = 8 waves as 2 (M) x 4 (N); output tile 192 pixels x (64 * NS)
-// channels; each wave owns 6 x NS 16x16 accumulator tiles. The input patch (tile rows + halo,
+// Workgroup = 512 threads = 8 waves; each wave owns 6 x NS 16x16 accumulator tiles (96 pixels x 16 NS channels).
+// bf16: waves 4 (M) x 2 (N), "tall" output tile 384 pixels x 128 channels; f32: 2 (M) x 4 (N), 192 pixels x (64 * NS)
+// channels (struct Cfg, WM). The input patch (tile rows + halo,
 // one 128-byte channel chunk per pixel) is parked in LDS ONCE per channel chunk and serves all
 // nine taps as shifted reads -- no im2col copy; weights stream through a double-buffered LDS
 // tile per (tap, chunk) with the next slice in flight (registers) behind the MFMAs. M-subtiles
