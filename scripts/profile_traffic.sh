@@ -14,7 +14,7 @@ cd $R
 python3 - <<'P'
 import collections, csv, glob, json, re
 CLIPS = 10240
-NAMES = {"Cfg<bf16, 64, 128, 48, 32, true, 2": "conv2", "Cfg<bf16, 128, 256, 24, 16, false, 4": "conv3", "Cfg<bf16, 256, 256, 24, 16, true, 4": "conv4",
+NAMES = {"Cfg<bf16, 64, 128, 48, 32, true, ": "conv2", "Cfg<bf16, 128, 256, 24, 16, false, 4": "conv3", "Cfg<bf16, 256, 256, 24, 16, true, 4": "conv4",
          "Cfg<bf16, 256, 512, 12, 8, false, 4": "conv5", "Cfg<bf16, 512, 512, 12, 8, true, 4": "conv6"}
 def collect(d, counter):
     acc = collections.defaultdict(list)
