@@ -82,7 +82,7 @@ def oracle_taps(sd, x, quant=None):
     return taps
 
 
-@pytest.mark.parametrize("n_frames", [2, 37])
+@pytest.mark.parametrize("n_frames", [2, 7, 37])       # tall W = 8 tiles hold 4 images: batch tails of 2, 3 and 1 images
 def test_conv_stack_layer_by_layer(ops, vg, W, mk, n_frames):
     sd_np = W.make_state_dict(1, W.vggish_shapes())
     sd = omodel.to_torch(sd_np)
