@@ -40,6 +40,12 @@ __device__ unsigned long long g_gemm_stamps[8][2][8];
 // tile's XOR swizzle applied on the source side) instead of through registers + ds_write: no staging registers, no
 // write pass in front of the barrier. Needs K % (64 or 32) == 0: an out-of-range DMA lane is dropped, not zero-filled
 // (rows past M / N only feed masked outputs; a K tail would feed valid ones).
+// timing experiment only (wrong results): -DMLA_GEMM_KWRAP=8 keeps every tile's operands inside 8 K stages, i.e. L2-resident
+#ifdef MLA_GEMM_KWRAP
+#define MLA_GEMM_KW(s) ((s) & (MLA_GEMM_KWRAP - 1))
+#else
+#define MLA_GEMM_KW(s) (s)
+#endif
 template <typename T, typename TO, int MS, int NS, bool RELU, bool DMA = false>
 __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__ A, int64_t lda,
                                                             const T* __restrict__ W, int64_t ldw,
@@ -117,13 +123,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
             const int row = 8 * (wave + 8 * p) + (lane >> 3);
             const int chunk = slot ^ (((row >> 1) & 3) << 1);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(sA + buf * A_BYTES + 8 * (wave + 8 * p) * kRowBytes),
-                                                     16, int((uint32_t(row) * uint32_t(lda) + chunk * PER) * ESZ), int(sa * KC * ESZ), 0, 0);
+                                                     16, int((uint32_t(row) * uint32_t(lda) + chunk * PER) * ESZ), int(MLA_GEMM_KW(sa) * KC * ESZ), 0, 0);
         }
         _Pragma("unroll") for (int p = 0; p < BN / 64; ++p) {
             const int row = 8 * (wave + 8 * p) + (lane >> 3);
             const int chunk = slot ^ (((row >> 1) & 3) << 1);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(sB + buf * B_BYTES + 8 * (wave + 8 * p) * kRowBytes),
-                                                     16, int((uint32_t(row) * uint32_t(ldw) + chunk * PER) * ESZ), int(s * KC * ESZ), 0, 0);
+                                                     16, int((uint32_t(row) * uint32_t(ldw) + chunk * PER) * ESZ), int(MLA_GEMM_KW(s) * KC * ESZ), 0, 0);
         }
     };
 
