@@ -40,6 +40,15 @@ namespace {
 
 using namespace logmel;
 
+// Diagnostic build only (-DMLA_LOGMEL_STAMPS=1, scripts/build_variant.py): wall-clock (s_memrealtime, 100 MHz) start / end stamp of
+// every workgroup, written to a buffer nothing else reads; read back through mla_debug_logmel_stamps(). The shipped kernel executes none.
+#ifndef MLA_LOGMEL_STAMPS
+#define MLA_LOGMEL_STAMPS 0
+#endif
+#if MLA_LOGMEL_STAMPS
+__device__ unsigned long long g_logmel_stamps[256][10];     // per workgroup: kernel entry, end of each of its 8 waves, loop start
+#endif
+
 constexpr int kPair = 2;                                  // STFT frames per 16-lane group and iteration (adjacent frames)
 constexpr int kChunk = 16 * kPair;                        // frames per workgroup iteration: a third of an example
 constexpr int kThreads = 256;
@@ -189,6 +198,57 @@ __device__ __forceinline__ void store_piece(OutT* dst, f32x4 v) {
     }
 }
 
+// One frame pair of a 16-lane group: window (samples already in `smp`), prefetch of the group's next pair, both FFTs, split,
+// mel, log, and the two finished rows to dst / dst + 64. Shared by the dynamic (shipped) and the static (cross-check) kernel.
+template <typename InT, typename OutT, bool VEC, bool WAVE>
+__device__ __forceinline__ void pair_step(const LaneConsts& c, int j, Samples<InT>& smp, const InT* next_frame, float* xa, float* xb,
+                                          const float* s_win, const float* melw, const float* pw, OutT* dst) {
+    float ra[16], ia[16], rb[16], ib[16];
+    {   // window: frame B's tap n1 is sample pair U[n1 + 5] under the SAME window value as A's tap n1
+        _Pragma("unroll") for (int n1 = 0; n1 < kN1; ++n1) {
+            const f32x2 w = *reinterpret_cast<const f32x2*>(s_win + 32 * n1 + 2 * j);   // zeros beyond 399
+            const f32x2 a = smp.pair(n1), b = smp.pair(n1 + 5);
+            ra[n1] = a.x * w.x; ia[n1] = a.y * w.y;
+            rb[n1] = b.x * w.x; ib[n1] = b.y * w.y;
+        }
+    }
+    if (next_frame) smp.template fetch<VEC>(next_frame, j);       // the next pair's samples fly while this one computes
+    phase1_fft(c, j, ra, ia, xa);
+    group_sync<WAVE>();
+    phase1_fft(c, j, rb, ib, xb);
+    group_sync<WAVE>();
+    // both rows and the split twiddles are requested together; A's second FFT starts when ITS eight reads are back
+    read_row(xa + 2 * (j * kXchStride), ra, ia);
+    read_row(xb + 2 * (j * kXchStride), rb, ib);
+    float pwl[16];
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {
+        const f32x2 q = *reinterpret_cast<const f32x2*>(pw + 2 * i);
+        pwl[2 * i] = q.x; pwl[2 * i + 1] = q.y;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    group_sync<WAVE>();                              // every lane has requested its rows: both buffers are dead
+    phase2_fft(ra, ia);
+    split_frame<WAVE>(j, ra, ia, xa, pwl);           // magnitudes of A overwrite its buffer
+    phase2_fft(rb, ib);
+    split_frame<WAVE>(j, rb, ib, xb, pwl);
+    group_sync<WAVE>();
+    float oa[4], ob[4];
+    mel_pair(c, xa, xb, melw, oa, ob);
+    // finished rows -> floats 256..319 of the (dead) buffers, then one 16-byte piece per lane and row:
+    // a wave stores its eight rows as 2 KiB contiguous
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) { xa[256 + band_of(j, s)] = oa[s]; xb[256 + band_of(j, s)] = ob[s]; }
+    group_sync<WAVE>();
+    {
+        const f32x4 va = *reinterpret_cast<const f32x4*>(xa + 256 + 4 * j);
+        const f32x4 vb = *reinterpret_cast<const f32x4*>(xb + 256 + 4 * j);
+        store_piece<OutT>(dst + 4 * j, va);
+        store_piece<OutT>(dst + kBands + 4 * j, vb);
+    }
+    group_sync<WAVE>();                 // the buffers are rewritten by the next pair
+}
+
+// Static kernel (cross-check build, MLA_LOGMEL_SYNC=block, and the round-1 schedule): 256 threads, two workgroups per CU, chunks of
+// 32 frames dealt grid-stride; WAVE = false keeps a full workgroup barrier at every hand-off.
 template <typename InT, typename OutT, bool VEC, bool WAVE>
 __global__ __launch_bounds__(kThreads, kWgPerCu) void logmel_kernel(const InT* __restrict__ pcm, ChunkMap map,
                                                               int64_t n_chunks, const float* __restrict__ tab,
@@ -210,7 +270,7 @@ __global__ __launch_bounds__(kThreads, kWgPerCu) void logmel_kernel(const InT* _
     for (int i = t; i < kWinFloats; i += kThreads) s_win[i] = tab[kTabWindow + i];
     const float* melw = s_mel + kMelRow * j;
     const float* pw = s_pw + kPwPitch * j;
-    __syncthreads();                        // the only workgroup barrier: tables visible
+    __syncthreads();                        // tables visible
 
     Samples<InT> smp;
     int64_t chunk = blockIdx.x, sample0, row0;
@@ -220,60 +280,105 @@ __global__ __launch_bounds__(kThreads, kWgPerCu) void logmel_kernel(const InT* _
     }
     for (; chunk < n_chunks; chunk += gridDim.x) {
         map.locate(chunk, sample0, row0);
-        float ra[16], ia[16], rb[16], ib[16];
-        {   // window: frame B's tap n1 is sample pair U[n1 + 5] under the SAME window value as A's tap n1
-            _Pragma("unroll") for (int n1 = 0; n1 < kN1; ++n1) {
-                const f32x2 w = *reinterpret_cast<const f32x2*>(s_win + 32 * n1 + 2 * j);   // zeros beyond 399
-                const f32x2 a = smp.pair(n1), b = smp.pair(n1 + 5);
-                ra[n1] = a.x * w.x; ia[n1] = a.y * w.y;
-                rb[n1] = b.x * w.x; ib[n1] = b.y * w.y;
-            }
-        }
         const int64_t next = chunk + gridDim.x;
-        if (next < n_chunks) {              // the next pair's samples fly while this one computes
+        const InT* next_frame = nullptr;
+        if (next < n_chunks) {
             int64_t ns, nr;
             map.locate(next, ns, nr);
-            smp.template fetch<VEC>(pcm + ns + (kPair * g) * kHop, j);
+            next_frame = pcm + ns + (kPair * g) * kHop;
         }
-        phase1_fft(c, j, ra, ia, xa);
-        group_sync<WAVE>();
-        phase1_fft(c, j, rb, ib, xb);
-        group_sync<WAVE>();
-        // both rows and the split twiddles are requested together; A's second FFT starts when ITS eight reads are back
-        read_row(xa + 2 * (j * kXchStride), ra, ia);
-        read_row(xb + 2 * (j * kXchStride), rb, ib);
-        float pwl[16];
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) {
-            const f32x2 q = *reinterpret_cast<const f32x2*>(pw + 2 * i);
-            pwl[2 * i] = q.x; pwl[2 * i + 1] = q.y;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        group_sync<WAVE>();                              // every lane has requested its rows: both buffers are dead
-        phase2_fft(ra, ia);
-        split_frame<WAVE>(j, ra, ia, xa, pwl);           // magnitudes of A overwrite its buffer
-        phase2_fft(rb, ib);
-        split_frame<WAVE>(j, rb, ib, xb, pwl);
-        group_sync<WAVE>();
-        float oa[4], ob[4];
-        mel_pair(c, xa, xb, melw, oa, ob);
-        // finished rows -> floats 256..319 of the (dead) buffers, then one 16-byte piece per lane and row:
-        // a wave stores its eight rows as 2 KiB contiguous
-        _Pragma("unroll") for (int s = 0; s < 4; ++s) { xa[256 + band_of(j, s)] = oa[s]; xb[256 + band_of(j, s)] = ob[s]; }
-        group_sync<WAVE>();
-        {
-            const f32x4 va = *reinterpret_cast<const f32x4*>(xa + 256 + 4 * j);
-            const f32x4 vb = *reinterpret_cast<const f32x4*>(xb + 256 + 4 * j);
-            OutT* dst = out + (row0 + kPair * g) * kBands + 4 * j;
-            store_piece<OutT>(dst, va);
-            store_piece<OutT>(dst + kBands, vb);
-        }
-        group_sync<WAVE>();                 // the buffers are rewritten by the next pair
+        pair_step<InT, OutT, VEC, WAVE>(c, j, smp, next_frame, xa, xb, s_win, melw, pw, out + (row0 + kPair * g) * kBands);
     }
+}
+
+// Dynamic kernel (shipped): ONE 512-thread workgroup per CU; work item = 8 frames = one wave-iteration (4 groups x 2 frames). A
+// workgroup owns a contiguous range of items and its 8 waves PULL them from an LDS counter. Why: with equal static shares the two
+// waves of a SIMD do not advance equally -- vector issue is arbitrated by age, the older wave runs ~1.5x faster, finishes its share
+// early and leaves its partner alone on the SIMD for the last third of the kernel (a single wave issues at half the pair's rate):
+// wall-clock stamps of the static kernel showed the first-dispatched workgroup of every CU done at 225-233 us and the second at
+// 335-355 us of a 358 us launch (profiles/r02_frontend_counters.txt). No workgroup barrier after the table load, no global state.
+constexpr int kThreadsDyn = 512;
+constexpr int kItemFrames = 4 * kPair;                     // frames per wave-iteration
+constexpr int kLdsFloatsDyn = (kThreadsDyn / 16) * kPair * kXchFloats + 16 * kMelRow + 16 * kPwPitch + kWinFloats + 4;
+constexpr int kLdsBytesDyn = kLdsFloatsDyn * 4;
+static_assert(kLdsBytesDyn <= 160 * 1024 && kChunk % kItemFrames == 0, "dynamic kernel: LDS / item size");
+
+template <typename InT, typename OutT, bool VEC>
+__global__ __launch_bounds__(kThreadsDyn, 1) void logmel_dyn_kernel(const InT* __restrict__ pcm, ChunkMap map, int64_t n_items,
+                                                                    const float* __restrict__ tab, OutT* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_xch = smem;
+    float* s_mel = s_xch + (kThreadsDyn / 16) * kPair * kXchFloats;
+    float* s_pw = s_mel + 16 * kMelRow;
+    float* s_win = s_pw + 16 * kPwPitch;
+    int* s_next = reinterpret_cast<int*>(s_win + kWinFloats);
+
+    const int t = threadIdx.x, g = t >> 4, gl = g & 3, j = t & 15, lane = t & 63;
+#if MLA_LOGMEL_STAMPS
+    const unsigned long long stamp_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+    float* xa = s_xch + (kPair * g) * kXchFloats;
+    float* xb = xa + kXchFloats;
+
+    LaneConsts c;
+    load_consts(c, tab, j);
+    for (int i = t; i < 16 * kMelRow; i += kThreadsDyn) s_mel[i] = tab[kTabMelW + i];
+    for (int i = t; i < 16 * kPwRow; i += kThreadsDyn) s_pw[(i >> 4) * kPwPitch + (i & 15)] = tab[kTabPw + i];
+    for (int i = t; i < kWinFloats; i += kThreadsDyn) s_win[i] = tab[kTabWindow + i];
+    // this workgroup's contiguous share of the items (consecutive frames: the 2.5x frame overlap stays in this XCD's L2)
+    const int lo = int(n_items * int64_t(blockIdx.x) / int64_t(gridDim.x)), hi = int(n_items * (int64_t(blockIdx.x) + 1) / int64_t(gridDim.x));
+    if (t == 0) *s_next = lo;
+    const float* melw = s_mel + kMelRow * j;
+    const float* pw = s_pw + kPwPitch * j;
+    __syncthreads();                        // the only workgroup barrier: tables and the counter visible
+
+    auto pull = [&]() {                      // wave-uniform: one lane takes the next item of the workgroup's share
+        int v = 0;
+        if (lane == 0) v = atomicAdd(s_next, 1);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    constexpr int kQ = kChunk / kItemFrames;                  // items per 32-frame chunk of the chunk map
+    auto locate_item = [&](int item, int64_t& sample, int64_t& row) {     // wave-uniform: first sample / output row of the item
+        int64_t sample0, row0;
+        map.locate(item / kQ, sample0, row0);
+        const int f = (item % kQ) * kItemFrames;
+        sample = sample0 + int64_t(f) * kHop;
+        row = row0 + f;
+    };
+    const int lane_frame = kPair * gl;                        // this group's frame pair inside the item
+    Samples<InT> smp;
+    int cur = pull();
+    int64_t sample = 0, row = 0;
+    if (cur < hi) {
+        locate_item(cur, sample, row);
+        smp.template fetch<VEC>(pcm + sample + lane_frame * kHop, j);
+    }
+#if MLA_LOGMEL_STAMPS
+    const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    while (cur < hi) {
+        const int nxt = pull();
+        int64_t nsample = 0, nrow = 0;
+        const InT* next_frame = nullptr;
+        if (nxt < hi) {
+            locate_item(nxt, nsample, nrow);
+            next_frame = pcm + nsample + lane_frame * kHop;
+        }
+        pair_step<InT, OutT, VEC, true>(c, j, smp, next_frame, xa, xb, s_win, melw, pw, out + (row + lane_frame) * kBands);
+        cur = nxt;
+        row = nrow;
+    }
+#if MLA_LOGMEL_STAMPS
+    if (lane == 0 && blockIdx.x < 256) {
+        if (t == 0) { g_logmel_stamps[blockIdx.x][0] = stamp_entry; g_logmel_stamps[blockIdx.x][9] = stamp0; }
+        g_logmel_stamps[blockIdx.x][1 + (t >> 6)] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 template <typename InT, typename OutT>
 int launch(const void* pcm, int64_t n_wave, int64_t wave_stride, int64_t examples, const float* tables,
-           void* out, bool wave_sync, hipStream_t stream) {
+           void* out, bool wave_sync, bool static_wave, hipStream_t stream) {
     const int64_t n_chunks = n_wave * examples * (kExFrames / kChunk);
     if (n_chunks == 0) return MLA_OK;
     const bool vec = mla::aligned(pcm, 2 * sizeof(InT)) && (wave_stride % 2 == 0);
@@ -289,11 +394,30 @@ int launch(const void* pcm, int64_t n_wave, int64_t wave_stride, int64_t example
         MLA_LAUNCH_OK("logmel_kernel");
         return MLA_OK;
     };
-    if (vec) return wave_sync ? go(logmel_kernel<InT, OutT, true, true>) : go(logmel_kernel<InT, OutT, true, false>);
-    return wave_sync ? go(logmel_kernel<InT, OutT, false, true>) : go(logmel_kernel<InT, OutT, false, false>);
+    if (wave_sync && !static_wave) {            // shipped: one 512-thread workgroup per CU, waves pull 8-frame items from an LDS counter
+        const int64_t n_items = n_chunks * (kChunk / kItemFrames);
+        MLA_REQUIRE(n_items <= 0x7fffffff, MLA_E_SHAPE, "too many frames for one launch (%lld items)", (long long)n_items);
+        const int64_t wgs = (n_items + 7) / 8 < cus ? (n_items + 7) / 8 : cus;
+        auto god = [&](auto kern) -> int {
+            MLA_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesDyn));
+            hipLaunchKernelGGL(kern, dim3(unsigned(wgs)), dim3(kThreadsDyn), kLdsBytesDyn, stream,
+                               static_cast<const InT*>(pcm), map, n_items, tables, static_cast<OutT*>(out));
+            MLA_LAUNCH_OK("logmel_dyn_kernel");
+            return MLA_OK;
+        };
+        return vec ? god(logmel_dyn_kernel<InT, OutT, true>) : god(logmel_dyn_kernel<InT, OutT, false>);
+    }
+    if (static_wave) return vec ? go(logmel_kernel<InT, OutT, true, true>) : go(logmel_kernel<InT, OutT, false, true>);
+    return vec ? go(logmel_kernel<InT, OutT, true, false>) : go(logmel_kernel<InT, OutT, false, false>);
 }
 
 }  // namespace
+
+#if MLA_LOGMEL_STAMPS
+extern "C" int mla_debug_logmel_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_logmel_stamps), sizeof(g_logmel_stamps)) == hipSuccess ? 0 : -4;
+}
+#endif
 
 extern "C" int mla_logmel_counts(int64_t n_samples, int64_t* stft_frames, int64_t* examples) {
     // mel_features.py:42: 1 + int(floor((n - 400) / 160)); negative counts raise in as_strided.
@@ -341,13 +465,15 @@ extern "C" int mla_logmel_examples(const void* pcm, int pcm_dtype, int64_t n_wav
     MLA_REQUIRE(pcm_dtype == MLA_F32 || pcm_dtype == MLA_I16, MLA_E_DTYPE, "pcm_dtype %d", pcm_dtype);
     MLA_REQUIRE(out_dtype == MLA_F32 || out_dtype == MLA_BF16, MLA_E_DTYPE, "out_dtype %d", out_dtype);
     MLA_REQUIRE(mla::aligned(pcm, pcm_dtype == MLA_F32 ? 4 : 2), MLA_E_ARG, "pcm misaligned for its dtype");
-    const char* env = getenv("MLA_LOGMEL_SYNC");            // "block" = cross-check build of the group sync
-    const bool wave_sync = !(env && env[0] == 'b');
+    // MLA_LOGMEL_SYNC: "block" = cross-check build of the group sync (static kernel, full barriers); "static" = the round-1
+    // schedule (static shares, wave-level fences) for A/B against the shipped dynamic kernel
+    const char* env = getenv("MLA_LOGMEL_SYNC");
+    const bool wave_sync = !(env && env[0] == 'b'), static_wave = env && env[0] == 's';
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (pcm_dtype == MLA_F32) {
-        return out_dtype == MLA_F32 ? launch<float, float>(pcm, n_wave, wave_stride, examples, tables, out, wave_sync, s)
-                                    : launch<float, __hip_bfloat16>(pcm, n_wave, wave_stride, examples, tables, out, wave_sync, s);
+        return out_dtype == MLA_F32 ? launch<float, float>(pcm, n_wave, wave_stride, examples, tables, out, wave_sync, static_wave, s)
+                                    : launch<float, __hip_bfloat16>(pcm, n_wave, wave_stride, examples, tables, out, wave_sync, static_wave, s);
     }
-    return out_dtype == MLA_F32 ? launch<int16_t, float>(pcm, n_wave, wave_stride, examples, tables, out, wave_sync, s)
-                                : launch<int16_t, __hip_bfloat16>(pcm, n_wave, wave_stride, examples, tables, out, wave_sync, s);
+    return out_dtype == MLA_F32 ? launch<int16_t, float>(pcm, n_wave, wave_stride, examples, tables, out, wave_sync, static_wave, s)
+                                : launch<int16_t, __hip_bfloat16>(pcm, n_wave, wave_stride, examples, tables, out, wave_sync, static_wave, s);
 }
