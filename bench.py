@@ -502,7 +502,7 @@ def infer_mode(args, world, rank, device, ops):
                                     "ms": conv_t * 1e3,
                                     "per_kernel_frac": {k: round(clips_per_step * m * 1e6 / avg[k] / 1e12 / peak, 4)
                                                         for k, m in list(CONV_MFLOP.items()) + list(FC_MFLOP.items()) if k in avg}},
-            "roofline_frontend": {"bound": "hbm", "kernel": "logmel_kernel", "achieved": fe_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+            "roofline_frontend": {"bound": "hbm", "kernel": "logmel_dyn_kernel", "achieved": fe_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                   "frac": fe_gbps / PEAK_HBM_GBPS, "avg_launch_ms": avg["logmel"] * 1e3,
                                   "bytes_per_clip": FE_BYTES[fe_dtype],
                                   "traffic": t_fe["bytes_per_clip"] * clips_per_step if t_fe else None},

@@ -23,8 +23,8 @@ def collect(d, counter):
             if r["Counter_Name"] != counter:
                 continue
             k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("mma::bf16_t", "bf16")
-            if "logmel_kernel" in k:
-                acc["logmel/bf16" if "__hip_bfloat16" in k or "bf16" in k.split("logmel_kernel")[1][:40] else "logmel/f32"].append(float(r["Counter_Value"]))
+            if "logmel_dyn_kernel" in k or "logmel_kernel" in k:
+                acc["logmel/bf16" if "__hip_bfloat16" in k or "bf16" in k.split("_kernel")[1][:40] else "logmel/f32"].append(float(r["Counter_Value"]))
             for pat, name in NAMES.items():
                 if "conv3x3_kernel<" + pat in k:
                     acc[name + "/bf16"].append(float(r["Counter_Value"]))
