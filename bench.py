@@ -182,8 +182,8 @@ def h2d_leg(pcm, step_s, clips_per_step, reps=5, ens=None):
     out = {"bytes": pcm.numel() * pcm.element_size(), "copy_ms": copy_s * 1e3, "GBps": pcm.numel() * pcm.element_size() / copy_s / 1e9,
            "clips_per_s_serial": clips_per_step / (copy_s + step_s), "clips_per_s_overlapped_bound": clips_per_step / max(copy_s, step_s),
            "pcm": str(pcm.dtype).replace("torch.", "") + ", pinned host memory"}
-    if ens is not None:            # measured: Ensemble.stream_waveforms (copy stream + two device buffers) over 8 host batches
-        n = 8
+    if ens is not None:            # measured: Ensemble.stream_waveforms (copy stream + two device buffers) over 24 host batches
+        n = 24                     # (the first batch's copy is not overlapped: 1 / n of the stream is pipeline fill)
         with torch.no_grad():
             for _ in ens.stream_waveforms([host] * 2):
                 pass
