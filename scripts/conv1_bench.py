@@ -1,3 +1,4 @@
+"""conv1 micro-benchmark: the first VGGish layer alone (bf16 / f32 output) on a 10 240-clip batch, HIP-event timing."""
 import importlib, os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

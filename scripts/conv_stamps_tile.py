@@ -1,3 +1,5 @@
+"""Diagnostic: tile-boundary cycles of the conv kernel (flush of the carried-over burst, epilogue) from s_memtime stamps
+(build: scripts/build_variant.py tstamps --only=conv.hip -DMLA_CONV_STAMPS=2 -DMLA_STAMP_TAP=4 -DMLA_STAMP_CHUNK=5; run with MLA_HIP_LIB)."""
 import ctypes, importlib, os, sys
 sys.path.insert(0, "/root/repo" if os.path.exists("/root/repo/bench.py") else os.getcwd())
 import torch

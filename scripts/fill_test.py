@@ -1,3 +1,4 @@
+"""Calibration: how long a plain fill / copy of conv1's 2 GB output takes on this chip (the store-bound floor of conv1)."""
 import torch, time
 x = torch.empty(10240*48*32*64, dtype=torch.bfloat16, device="cuda")
 y = torch.empty_like(x)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# round-1 recipe: bench line + rocprofv3 --kernel-trace --stats of the same command (round 2: scripts/profile_round.sh)
 set -e
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,4 +1,5 @@
 #!/bin/bash
+# round-1 recipe: MFMA-pipe / wave-state counters of the conv micro-benchmark, one --pmc pass per layer (round 2: scripts/profile_mfma_counters.sh)
 set -e
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,4 +1,5 @@
 #!/bin/bash
+# rocprofv3 --pmc passes on the fused log-mel kernel alone (target scripts/fe_prof.py): HBM traffic, wave states, LDS array (profiles/r01_frontend_counters.txt)
 set -e
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
