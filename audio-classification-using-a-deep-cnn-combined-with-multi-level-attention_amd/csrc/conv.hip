@@ -23,6 +23,7 @@
 //   W >= 16 : an m-subtile = 16 consecutive x of one image row; rows y / y+1 are the wave's
 //             subtiles i / i+1, x pairs are accumulator registers (0,1) / (2,3);
 //   W == 8  : an m-subtile = 8 x of image a + 8 x of image a+1 (same row).
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -863,6 +864,11 @@ __global__ void widen_kernel(const bf16_t* __restrict__ in, float* __restrict__ 
         out[i] = bf2f(in[i].bits);
 }
 
+inline bool wide_tiles() {
+    const char* e = getenv("MLA_CONV_TILE");
+    return e && e[0] == 'w';
+}
+
 template <typename C>
 int launch_conv(const void* in, const void* w, const float* bias, void* out, int64_t n_img, hipStream_t s, void* prepool = nullptr) {
     using T = typename C::elem;
@@ -888,8 +894,10 @@ int launch_conv(const void* in, const void* w, const float* bias, void* out, int
 
 template <typename T>
 int conv_layer(int layer, const void* in, const void* w, const float* bias, void* out, int64_t n, hipStream_t s) {
-    if constexpr (sizeof(T) == 2 && MLA_CONV_TALL) {     // bf16, W >= 16: tall tiles (384 pixels x 128 channels)
-        switch (layer) {
+    // MLA_CONV_TILE=wide selects the 192-pixel tiles at run time: same products in the same order per accumulator, i.e. bit-identical
+    // results (tests/test_model_gpu.py checks that), for A/B timing and as the cross-check of the tall tiles' index arithmetic
+    if constexpr (sizeof(T) == 2 && MLA_CONV_TALL) {     // bf16: tall tiles (384 pixels x 128 channels)
+        if (!wide_tiles()) switch (layer) {
             case 2: return launch_conv<Cfg<T, 64, 128, 48, 32, true, 4, true, false, 4>>(in, w, bias, out, n, s);
             case 3: return launch_conv<Cfg<T, 128, 256, 24, 16, false, 4, true, false, 4>>(in, w, bias, out, n, s);
             case 4: return launch_conv<Cfg<T, 256, 256, 24, 16, true, 4, true, false, 4>>(in, w, bias, out, n, s);
@@ -910,15 +918,13 @@ int conv_layer(int layer, const void* in, const void* w, const float* bias, void
 }
 
 int conv_layer_split(int layer, const void* in, const void* w, const float* bias, void* out, int64_t n, hipStream_t s) {
-#if MLA_CONV_TALL_SPLIT
-    switch (layer) {
+    if (MLA_CONV_TALL_SPLIT && !wide_tiles()) switch (layer) {
         case 2: return launch_conv<Cfg<bf16_t, 64, 128, 48, 32, true, 4, true, true, 4>>(in, w, bias, out, n, s);
         case 3: return launch_conv<Cfg<bf16_t, 128, 256, 24, 16, false, 4, true, true, 4>>(in, w, bias, out, n, s);
         case 4: return launch_conv<Cfg<bf16_t, 256, 256, 24, 16, true, 4, true, true, 4>>(in, w, bias, out, n, s);
         case 5: return launch_conv<Cfg<bf16_t, 256, 512, 12, 8, false, 4, true, true, 4>>(in, w, bias, out, n, s);
         case 6: return launch_conv<Cfg<bf16_t, 512, 512, 12, 8, true, 4, true, true, 4>>(in, w, bias, out, n, s);
     }
-#else
     switch (layer) {
         case 2: return launch_conv<Cfg<bf16_t, 64, 128, 48, 32, true, 2, true, true>>(in, w, bias, out, n, s);
         case 3: return launch_conv<Cfg<bf16_t, 128, 256, 24, 16, false, 4, true, true>>(in, w, bias, out, n, s);
@@ -926,7 +932,6 @@ int conv_layer_split(int layer, const void* in, const void* w, const float* bias
         case 5: return launch_conv<Cfg<bf16_t, 256, 512, 12, 8, false, 4, true, true>>(in, w, bias, out, n, s);
         case 6: return launch_conv<Cfg<bf16_t, 512, 512, 12, 8, true, 4, true, true>>(in, w, bias, out, n, s);
     }
-#endif
     return mla::fail(MLA_E_SHAPE, "conv layer %d is not one of VGGish conv2..conv6", layer);
 }
 
@@ -954,9 +959,9 @@ int conv_generic(const void* in, const void* w, const float* bias, void* out, in
 #define MLA_CONV_CASE_TALL(CI, CO, HH, WW, PO, NS_, AC)                                                        \
     if (cin == CI && cout == CO && H == HH && W == WW && pool == PO && act == AC) {                            \
         if constexpr (sizeof(T) == 2 && MLA_CONV_TALL)                                                         \
-            return launch_conv<Cfg<T, CI, CO, HH, WW, PO, 4, AC, false, 4>>(in, w, bias, out, n, s, prepool);  \
-        else                                                                                                   \
-            return launch_conv<Cfg<T, CI, CO, HH, WW, PO, NS_, AC>>(in, w, bias, out, n, s, prepool);          \
+            if (!wide_tiles())                                                                                 \
+                return launch_conv<Cfg<T, CI, CO, HH, WW, PO, 4, AC, false, 4>>(in, w, bias, out, n, s, prepool);  \
+        return launch_conv<Cfg<T, CI, CO, HH, WW, PO, NS_, AC>>(in, w, bias, out, n, s, prepool);              \
     }
 #if MLA_CONV_TALL >= 2
 #define MLA_CONV_CASE_TALL8 MLA_CONV_CASE_TALL

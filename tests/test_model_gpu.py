@@ -351,3 +351,31 @@ def test_linear_narrow_matches_float64_and_is_batch_independent(ops, W, M, N, K)
     assert torch.equal(one[0], got[M // 2])
     nob = ops.linear(a, w, None)
     assert rel_err(nob.cpu(), ref - b.double().cpu()) < 2e-6
+
+
+@pytest.mark.gpu
+def test_tall_and_wide_conv_tiles_are_bit_identical(ops, vg, W):
+    """bf16 / bf16x3 conv layers run 384-pixel x 128-channel tiles; MLA_CONV_TILE=wide selects round 1's 192-pixel tiles at run
+    time. Every accumulator receives the same products in the same order in both, so the whole stack must agree bit for bit --
+    the cross-check of the tall tiles' index arithmetic (four-image tiles at patch pitch 9, image tails of 1..3)."""
+    import os
+    sd_np = W.make_state_dict(1, W.vggish_shapes())
+    feats = load(vg.make_layers(), {k[len("features."):]: v for k, v in sd_np.items() if k.startswith("features.")})
+    for n in (7, 64):
+        x = torch.from_numpy(W.uniform(53, 9, n * 96 * 64, lo=-1.4, hi=4.6)).reshape(n, 96, 64).cuda()
+        tall = feats.forward_nhwc(x, torch.bfloat16)
+        os.environ["MLA_CONV_TILE"] = "wide"
+        try:
+            wide = feats.forward_nhwc(x, torch.bfloat16)
+        finally:
+            del os.environ["MLA_CONV_TILE"]
+        assert torch.equal(tall.view(torch.int16), wide.view(torch.int16)), "bf16, %d clips" % n
+        feats.precision = "bf16x3"                      # split mode: (N, 6, 4, 1024) = [hi | lo]
+        try:
+            tall3 = feats.forward_nhwc(x, torch.bfloat16)
+            os.environ["MLA_CONV_TILE"] = "wide"
+            wide3 = feats.forward_nhwc(x, torch.bfloat16)
+        finally:
+            os.environ.pop("MLA_CONV_TILE", None)
+            feats.precision = "f32"
+        assert tall3.shape[-1] == 1024 and torch.equal(tall3.view(torch.int16), wide3.view(torch.int16)), "bf16x3, %d clips" % n
