@@ -40,6 +40,9 @@ __device__ unsigned long long g_gemm_stamps[8][2][8];
 // tile's XOR swizzle applied on the source side) instead of through registers + ds_write: no staging registers, no
 // write pass in front of the barrier. Needs K % (64 or 32) == 0: an out-of-range DMA lane is dropped, not zero-filled
 // (rows past M / N only feed masked outputs; a K tail would feed valid ones).
+#ifndef MLA_GEMM_TILE320
+#define MLA_GEMM_TILE320 1
+#endif
 // timing experiment only (wrong results): -DMLA_GEMM_KWRAP=8 keeps every tile's operands inside 8 K stages, i.e. L2-resident
 #ifdef MLA_GEMM_KWRAP
 #define MLA_GEMM_KW(s) ((s) & (MLA_GEMM_KWRAP - 1))
@@ -322,6 +325,24 @@ int dispatch(const void* a, int64_t lda, const void* w, int64_t ldw, const float
              int64_t M, int64_t N, int64_t K, bool relu, hipStream_t s, int seg = 0, int osplit = 0) {
     const bool wide = N > 128 && (N % 256 == 0 || N % 256 > 128);     // 256-wide tiles unless they waste > half a tile
     const bool tall = wide && M >= 4096 && N >= 1024;                  // 256 x 256 tiles once they still fill the chip
+#if MLA_GEMM_TILE320
+    if (tall && K % mma::Elem<T>::kPerRow == 0) {      // LDS-DMA path only (the register-staged form of this tile spills)
+        // 320 x 256 tiles (waves 2 x 4, 10 x 4 accumulator tiles each): 10 240 rows x 4096 columns are 512 tiles = exactly two
+        // rounds on 256 CUs (256 x 256: 640 tiles = 2.5 rounds), and the tile moves 72 KB per K stage for 1.25x the FLOPs of the
+        // 64 KB one -- the GEMM is bound by the CU's L2 -> LDS fill rate (profiles/r02_conv_stamps.txt), so both count. Taken when
+        // its rounds x bytes per stage beat the 256-row tiling's (K order per output element unchanged: bit-identical).
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int64_t n_tiles = (N + 255) / 256;
+        const int64_t t256 = ((M + 255) / 256) * n_tiles, t320 = ((M + 319) / 320) * n_tiles;
+        const int64_t full = t256 / cus, rest = t256 - full * cus;
+        const double cost256 = 64.0 * double(full) + (rest == 0 ? 0.0 : (full >= 1 && 2 * rest <= cus && (full * cus) % n_tiles == 0 ? 48.0 : 64.0));
+        const double cost320 = 72.0 * double((t320 + cus - 1) / cus);
+        if (cost320 < cost256)
+            return relu ? launch<T, TO, 10, 4, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit)
+                        : launch<T, TO, 10, 4, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit);
+    }
+#endif
     if (tall) {
         // Tile quantisation: 256 x 256 tiles run one per CU, so e.g. 640 tiles on 256 CUs take 3 rounds for 2.5 rounds of
         // work. When the last round would be at most half full, the rows of the whole rounds keep the tall tiles and the
