@@ -84,6 +84,9 @@ __device__ unsigned long long g_conv_stamps[8][2][8];
 #ifndef MLA_CONV_TALL_SPLIT
 #define MLA_CONV_TALL_SPLIT 1
 #endif
+#ifndef MLA_CONV_NT_STORE
+#define MLA_CONV_NT_STORE 1              // streaming outputs (conv epilogues, conv1) as non-temporal stores: conv1 0.43 -> 0.38 ms, conv3 -4 % in the pipeline
+#endif
 #ifndef MLA_CONV_DMA_DIV
 #define MLA_CONV_DMA_DIV 1
 #endif
@@ -162,7 +165,11 @@ template <> __device__ __forceinline__ void store_vec<float, 2>(float* p, const 
     *reinterpret_cast<f32x2*>(p) = f32x2{v[0], v[1]};
 }
 template <> __device__ __forceinline__ void store_vec<bf16_t, 4>(bf16_t* p, const float* v) {
+#if MLA_CONV_NT_STORE
+    __builtin_nontemporal_store(u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, reinterpret_cast<u32x2*>(p));
+#else
     *reinterpret_cast<u32x2*>(p) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+#endif
 }
 template <> __device__ __forceinline__ void store_vec<bf16_t, 2>(bf16_t* p, const float* v) {
     *reinterpret_cast<uint32_t*>(p) = pack_bf16x2(v[0], v[1]);
@@ -830,7 +837,11 @@ __global__ __launch_bounds__(256, MLA_CONV1_WAVES) void conv1_patch_kernel(const
             char* gdst = reinterpret_cast<char*>(out + ((size_t(img) * 48 + y0 / 2 + prow) * 32) * 64);
             _Pragma("unroll") for (int it = 0; it < 4; ++it) {                      // 32 pixels x 128 B = 4 KiB contiguous per wave
                 const int piece = it * 64 + lane, p = piece >> 3, c = piece & 7;
+#if MLA_CONV_NT_STORE
+                __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(stage + p * ROW + c * 16), reinterpret_cast<u32x4*>(gdst + size_t(piece) * 16));
+#else
                 *reinterpret_cast<u32x4*>(gdst + size_t(piece) * 16) = *reinterpret_cast<const u32x4*>(stage + p * ROW + c * 16);
+#endif
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the reads above precede the next row's stage writes
             __builtin_amdgcn_wave_barrier();
