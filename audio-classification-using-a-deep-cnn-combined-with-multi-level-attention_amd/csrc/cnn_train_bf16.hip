@@ -14,7 +14,7 @@
 //                         activations ever exists. The order of the 32 pixels inside a k-step is chosen so that each
 //                         32-lane half reads 8 CONSECUTIVE pixel rows: with a 160-byte row pitch these are 8 distinct
 //                         32-byte bank slots -- conflict-free for every tap shift.
-//   conv1_bwd (bf16 dY)   Cin = 1 special case of cnn_train.hip with the incoming gradient in bf16
+//   conv1_bwd (bf16 dY)   recompute and weight gradient of the Cin = 1 layer as two GEMMs on the matrix cores (conv1_bwd_mfma_kernel)
 //   transpose_bf16, col_sum_bf16   helpers of the Linear backward (K-contiguous operands for the MFMA GEMM; bias gradients)
 //
 // Roofline: wgrad is MFMA-bound (2 * pixels * 9 Cin Cout flop per image, the same as the forward layer); the elementwise
@@ -427,6 +427,186 @@ __global__ __launch_bounds__(256) void conv1_bwd_finish_bf16_kernel(const float*
     }
 }
 
+// ---- conv1 backward on the matrix cores (round 2) ------------------------------------------------------------------------------
+// conv1 + ReLU + 2x2 max-pool as the patch GEMM of conv.hip (conv1_patch_kernel): pre[pos][c][P] = sum_k W'[pos][c][k] patch[k][P]
+// over the 4 x 4 input patch of pooled pixel P. Its weight gradient is a GEMM too: with g[P][c] = dY[P][c] where the pooled output
+// is positive and G_pos = g masked to the pixels whose first maximum sits at window position pos,
+//     dW'[pos] (64 x 16) = G_pos (64 x pixels) . patch^T (pixels x 16),     dW[c][ky][kx] = sum_pos dW'[pos][c][4 (dy + ky) + dx + kx].
+// One wave per pooled row (32 pixels): (1) RECOMPUTE pre^T[P][c] = patch^T W'^T on v_mfma_f32_16x16x32_bf16 (K = 16 patch elements,
+// zero-padded) with the same bf16 operands as the forward kernel; in the C/D layout a lane then holds ONE channel's values of 4
+// consecutive pixels, for each of the 4 positions -- arg-max, ReLU mask and the gradient (fetched with the transposing LDS read,
+// which delivers exactly one channel's 4 pixels per lane) are lane-local; (2) the masked gradients of two 16-pixel tiles ARE the A
+// fragment of the second GEMM (row = channel, k = 8 pixels) if its K index enumerates the row's pixels as {4q .. 4q+3, 16+4q ..
+// 16+4q+3} for lane group q -- K is a summation index, any order serves as long as the B operand (patch values) uses the same one.
+// No transpose, no per-lane 72-register accumulator file, 48 MFMAs per 32 pixels x 64 channels instead of ~82 vector instructions per
+// (pixel, channel). Deterministic: static row shares, waves of a workgroup added in order, workgroups summed in a fixed tree.
+#ifndef MLA_CONV1_BWD_MFMA
+#define MLA_CONV1_BWD_MFMA 1
+#endif
+constexpr int kC1Part = 4 * 64 * 16 + 64;                   // floats per workgroup partial: dW'[pos][c][k], db[c]
+constexpr int kC1MaxWg = 768;                               // persistent workgroups (3 per CU: 43 KB of LDS each)
+
+__global__ __launch_bounds__(256, 2) void conv1_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, const bf16_t* __restrict__ d_pooled,
+                                                             int n_seg, float* __restrict__ partial) {
+    constexpr int XP = 72;                                      // bf16 per staged input row: element (gy, gx) at column gx + 1
+    __shared__ __attribute__((aligned(16))) uint16_t sW[4 * 64 * 16];
+    __shared__ __attribute__((aligned(16))) uint16_t sX[4][4 * XP];
+    __shared__ __attribute__((aligned(16))) uint16_t sD[4][32 * 64];
+    __shared__ float sRed[kC1Part];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 15, q = lane >> 4, q4 = r >> 2, p4 = r & 3;
+
+    for (int i = t; i < 4 * 64 * 16; i += 256) {                // W'[pos][c][k]: the 3 x 3 filter at offset (dy, dx) inside the 4 x 4 patch
+        const int pos = i >> 10, ch = (i >> 4) & 63, e = i & 15;
+        const int ky = (e >> 2) - (pos >> 1), kx = (e & 3) - (pos & 1);
+        sW[i] = f2bf((ky >= 0 && ky < 3 && kx >= 0 && kx < 3) ? w[ch * 9 + ky * 3 + kx] : 0.f);
+    }
+    for (int i = t; i < kC1Part; i += 256) sRed[i] = 0.f;
+    __syncthreads();
+
+    f32x4 accw[4][4];                                           // dW'[pos][channel tile]: row = channel 4q + reg, col = patch element r
+    _Pragma("unroll") for (int pos = 0; pos < 4; ++pos)
+        _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) accw[pos][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbs[4] = {0.f, 0.f, 0.f, 0.f}, bch[4];
+    _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) bch[ct] = bias[16 * ct + r];
+    uint16_t* mx = sX[wave];
+    uint16_t* md = sD[wave];
+
+    for (int seg = int(blockIdx.x) * 4 + wave; seg < n_seg; seg += int(gridDim.x) * 4) {
+        const int n = seg / 48, py = seg % 48;
+        // stage: input rows 2py-1 .. 2py+2, columns -1 .. 64 (f32 -> bf16, zeros outside the image; unconditional clamped loads) and
+        // the row's 32 x 64 gradient tile (4 KiB contiguous). Three workgroups per CU hide the round trip; fetching a row ahead into
+        // registers cost the third wave per SIMD and measured slower (0.75 -> 0.94 ms).
+        _Pragma("unroll") for (int k = 0; k < 5; ++k) {
+            const int i = lane + 64 * k, row = i / 66, col = i % 66;
+            const int gy = 2 * py - 1 + row, gx = col - 1;
+            const int cy = gy < 0 ? 0 : (gy > 95 ? 95 : gy), cx = gx < 0 ? 0 : (gx > 63 ? 63 : gx);
+            const float v = x[(size_t(n) * 96 + cy) * 64 + cx];
+            if (i < 4 * 66) mx[row * XP + col] = f2bf((gy >= 0 && gy < 96 && gx >= 0 && gx < 64) ? v : 0.f);
+        }
+        const u32x4* gsrc = reinterpret_cast<const u32x4*>(d_pooled + size_t(seg) * 32 * 64);
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) reinterpret_cast<u32x4*>(md)[lane + 64 * k] = gsrc[lane + 64 * k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the staging buffers belong to this wave; its LDS
+        __builtin_amdgcn_wave_barrier();                            // operations execute in order
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // A fragments of the recompute: patch elements 8q .. 8q+7 (patch rows 2q, 2q+1) of pixel 16 pt + r; k >= 16 is padding
+        bf16x8 pa[2];
+        _Pragma("unroll") for (int pt = 0; pt < 2; ++pt) {
+            const int px = 16 * pt + r;
+            const uint32_t* r0 = reinterpret_cast<const uint32_t*>(mx + (2 * (q & 1)) * XP + 2 * px);
+            const uint32_t* r1 = reinterpret_cast<const uint32_t*>(mx + (2 * (q & 1) + 1) * XP + 2 * px);
+            const u32x4 ur{r0[0], r0[1], r1[0], r1[1]};
+            pa[pt] = __builtin_bit_cast(bf16x8, q < 2 ? ur : u32x4{0u, 0u, 0u, 0u});
+        }
+        // B fragment of the gradient GEMM: patch element r of the 8 pixels {4q .. 4q+3, 16+4q .. 16+4q+3}
+        bf16x8 pb;
+        {
+            const uint16_t* base = mx + (r >> 2) * XP + (r & 3);
+            uint16_t e[8];
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) e[j] = base[2 * ((j < 4 ? 0 : 16) + 4 * q + (j & 3))];
+            pb = __builtin_bit_cast(bf16x8, u32x4{uint32_t(e[0]) | (uint32_t(e[1]) << 16), uint32_t(e[2]) | (uint32_t(e[3]) << 16),
+                                                  uint32_t(e[4]) | (uint32_t(e[5]) << 16), uint32_t(e[6]) | (uint32_t(e[7]) << 16)});
+        }
+        _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) {
+            __builtin_amdgcn_sched_barrier(0);                      // one channel tile at a time: hoisting the next tile's operand reads
+                                                                    // up here costs ~90 registers (they went to AGPRs and back)
+            // (1) pre^T[pixel][channel] for the four window positions; D: col = channel 16 ct + r, row = pixel 4q + reg
+            f32x4 pre[4][2];
+            _Pragma("unroll") for (int pos = 0; pos < 4; ++pos) {
+                // K slots 16 .. 31 are padding: lanes q >= 2 read a valid address and select zero (no branch around the read)
+                const u32x4 bwr = *reinterpret_cast<const u32x4*>(sW + ((pos * 64 + 16 * ct + r) * 16 + 8 * (q & 1)));
+                const u32x4 bw = q < 2 ? bwr : u32x4{0u, 0u, 0u, 0u};
+                _Pragma("unroll") for (int pt = 0; pt < 2; ++pt)
+                    pre[pos][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[pt], __builtin_bit_cast(bf16x8, bw),
+                                                                           f32x4{bch[ct], bch[ct], bch[ct], bch[ct]}, 0, 0, 0);
+            }
+            // (2) this lane's channel: first maximum, ReLU mask, routed gradient for its 2 x 4 pixels. Lane-mask logic (scalar ALU) picks
+            // the position; the bf16 gradient halves are masked in place (dY is bf16 already: the masked copy is exact)
+            uint32_t gp[4][4];                                   // [pos][pixel pair] packed bf16 pairs = the A fragment's dwords
+            _Pragma("unroll") for (int pt = 0; pt < 2; ++pt) {
+                const s16x4 dv = tr_read(reinterpret_cast<const char*>(md + ((16 * pt + 4 * q + q4) * 64 + 16 * ct + 4 * p4)));
+                const u32x2 dw = __builtin_bit_cast(u32x2, dv);      // pixels (0, 1) and (2, 3) of this lane's channel
+                _Pragma("unroll") for (int pr = 0; pr < 2; ++pr) {
+                    uint32_t sel[4][2];                          // [pos][half]: the half's bits if the first maximum is at pos
+                    _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {
+                        const int e = 2 * pr + hf;
+                        const float p0 = pre[0][pt][e], p1 = pre[1][pt][e], p2 = pre[2][pt][e], p3 = pre[3][pt][e];
+                        const bool m1 = p1 > p0;
+                        const float b1 = m1 ? p1 : p0;
+                        const bool m2 = p2 > b1;
+                        const float b2 = m2 ? p2 : b1;
+                        const bool m3 = p3 > b2;
+                        const float b3 = m3 ? p3 : b2;
+                        const bool on = b3 > 0.f;
+                        const uint32_t bits = hf ? (dw[pr] & 0xffff0000u) : (dw[pr] & 0xffffu);
+                        const uint32_t gbits = on ? bits : 0u;
+                        dbs[ct] += __builtin_bit_cast(float, hf ? gbits : (gbits << 16));
+                        sel[3][hf] = m3 ? gbits : 0u;
+                        sel[2][hf] = (m2 && !m3) ? gbits : 0u;
+                        sel[1][hf] = (m1 && !m2 && !m3) ? gbits : 0u;
+                        sel[0][hf] = (!m1 && !m2 && !m3) ? gbits : 0u;
+                    }
+                    _Pragma("unroll") for (int pos = 0; pos < 4; ++pos) gp[pos][2 * pt + pr] = sel[pos][0] | sel[pos][1];
+                }
+            }
+            // (3) dW'[pos][channel][element] += G_pos . patch^T
+            _Pragma("unroll") for (int pos = 0; pos < 4; ++pos)
+                accw[pos][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, u32x4{gp[pos][0], gp[pos][1], gp[pos][2], gp[pos][3]}), pb, accw[pos][ct], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the reads above precede the next row's staging writes
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // db: the 4 lane groups hold different pixels of the same channel
+    _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) {
+        dbs[ct] += __shfl_xor(dbs[ct], 16);
+        dbs[ct] += __shfl_xor(dbs[ct], 32);
+    }
+    // the workgroup's four waves, added in order
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+            _Pragma("unroll") for (int pos = 0; pos < 4; ++pos)
+                _Pragma("unroll") for (int ct = 0; ct < 4; ++ct)
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e)
+                        sRed[(pos * 64 + 16 * ct + 4 * q + e) * 16 + r] += accw[pos][ct][e];
+            if (q == 0)
+                _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) sRed[4096 + 16 * ct + r] += dbs[ct];
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < kC1Part; i += 256) partial[size_t(blockIdx.x) * kC1Part + i] = sRed[i];
+}
+
+// dW[c][ky][kx] = sum over workgroups and positions of dW'[pos][c][4 (dy + ky) + dx + kx]; db[c]: one workgroup per output
+__global__ __launch_bounds__(256) void conv1_bwd_mfma_finish_kernel(const float* __restrict__ partial, int blocks, float* __restrict__ dw,
+                                                                    float* __restrict__ db) {
+    __shared__ double part[256];
+    const int i = blockIdx.x;                                      // 0 .. 639: channel * 10 + (tap | bias)
+    const int c = i / 10, k = i % 10;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += 256) {
+        const float* p = partial + size_t(b) * kC1Part;
+        if (k == 9) {
+            s += p[4096 + c];
+        } else {
+            const int ky = k / 3, kx = k % 3;
+            _Pragma("unroll") for (int pos = 0; pos < 4; ++pos) s += p[(pos * 64 + c) * 16 + 4 * ((pos >> 1) + ky) + (pos & 1) + kx];
+        }
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int wv = 128; wv > 0; wv >>= 1) {
+        if (int(threadIdx.x) < wv) part[threadIdx.x] += part[threadIdx.x + wv];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (k < 9) dw[c * 9 + k] = float(part[0]);
+        else db[c] = float(part[0]);
+    }
+}
+
 // ------------------------------------------------------------------- Linear-backward helpers ---
 // out[c][r] = in[r][c] for 2-byte elements; 64 x 64 tiles through LDS
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __restrict__ in, int64_t ld_in, uint16_t* __restrict__ out,
@@ -541,17 +721,33 @@ extern "C" int mla_conv_wgrad_bf16(const void* dz, const void* a_in, int64_t n, 
     return mla::fail(MLA_E_SHAPE, "wgrad %dx%d %d->%d is not compiled", H, W, cin, cout);
 }
 
+extern "C" int64_t mla_conv1_bwd_workspace_floats(void) {
+    const int64_t a = int64_t(1024) * 8 * 80, b = int64_t(kC1MaxWg) * kC1Part;       // f32 form (cnn_train.hip) / bf16 MFMA form
+    return a > b ? a : b;
+}
+
 extern "C" int mla_conv1_bwd_bf16(const float* x, const float* w, const float* bias, const void* d_pooled, int64_t n, float* workspace,
                                   float* dw, float* db, mla_stream_t stream) {
     MLA_REQUIRE(x && w && bias && d_pooled && workspace && dw && db && n > 0, MLA_E_ARG, "bad conv1_bwd arguments");
     const int64_t n_pix = n * 48 * 32;
-    const int blocks = int((n_pix + 255) / 256 < 1024 ? (n_pix + 255) / 256 : 1024);
     hipStream_t s = static_cast<hipStream_t>(stream);
+#if MLA_CONV1_BWD_MFMA
+    MLA_REQUIRE(n * 48 <= 0x7fffffff, MLA_E_SHAPE, "too many rows for one launch");
+    const int n_seg = int(n * 48);
+    const int wgs = (n_seg + 3) / 4 < kC1MaxWg ? (n_seg + 3) / 4 : kC1MaxWg;      // workspace: kC1MaxWg * kC1Part floats
+    hipLaunchKernelGGL(conv1_bwd_mfma_kernel, dim3(wgs), dim3(256), 0, s, x, w, bias, static_cast<const bf16_t*>(d_pooled), n_seg, workspace);
+    MLA_LAUNCH_OK("conv1_bwd_mfma");
+    hipLaunchKernelGGL(conv1_bwd_mfma_finish_kernel, dim3(640), dim3(256), 0, s, workspace, wgs, dw, db);
+    MLA_LAUNCH_OK("conv1_bwd_mfma_finish");
+    return MLA_OK;
+#else
+    const int blocks = int((n_pix + 255) / 256 < 1024 ? (n_pix + 255) / 256 : 1024);
     hipLaunchKernelGGL(conv1_bwd_bf16_kernel, dim3(blocks, 8), dim3(256), 0, s, x, w, bias, static_cast<const bf16_t*>(d_pooled), n_pix, workspace);
     MLA_LAUNCH_OK("conv1_bwd_bf16");
     hipLaunchKernelGGL(conv1_bwd_finish_bf16_kernel, dim3(640), dim3(256), 0, s, workspace, blocks, dw, db);
     MLA_LAUNCH_OK("conv1_bwd_finish_bf16");
     return MLA_OK;
+#endif
 }
 
 extern "C" int mla_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int64_t cols,

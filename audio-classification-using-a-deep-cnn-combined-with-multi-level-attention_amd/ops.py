@@ -560,6 +560,6 @@ def conv_wgrad(dz, a_in, dw):
 def conv1_bwd(x, w, b, d_pooled, dw, db):
     _chk(x, torch.float32); _chk(d_pooled)
     n = x.shape[0]
-    ws = torch.empty(1024 * 8 * 80, dtype=torch.float32, device=x.device)
+    ws = torch.empty(int(_lib.lib().mla_conv1_bwd_workspace_floats()), dtype=torch.float32, device=x.device)
     fn = _lib.lib().mla_conv1_bwd_bf16 if d_pooled.dtype == torch.bfloat16 else _lib.lib().mla_conv1_bwd
     _lib.check(_timed("conv1_bwd", fn, _p(x), _p(w), _p(b), _p(d_pooled), n, _p(ws), _p(dw), _p(db), _lib.stream_ptr()))

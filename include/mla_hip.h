@@ -317,8 +317,11 @@ int mla_relu_pool_bwd_bf16(const void* a, int a_dtype, const void* d_out, int d_
  * read ds_read_b64_tr_b16); workspace as mla_conv_wgrad. */
 int mla_conv_wgrad_bf16(const void* dz, const void* a_in, int64_t n, int H, int W, int cin, int cout, float* workspace,
                         int64_t workspace_floats, float* dw_oihw, mla_stream_t stream);
+/* conv1 backward with the incoming gradient in bf16: recompute and weight-gradient products on the matrix cores (patch GEMM, see
+ * cnn_train_bf16.hip). workspace: mla_conv1_bwd_workspace_floats() floats (also enough for mla_conv1_bwd). */
 int mla_conv1_bwd_bf16(const float* x, const float* w, const float* bias, const void* d_pooled_bf16, int64_t n, float* workspace,
                        float* dw, float* db, mla_stream_t stream);
+int64_t mla_conv1_bwd_workspace_floats(void);
 /* (rows, cols) bf16 -> (cols, ld_out >= rows) bf16, the padding columns zeroed: K-contiguous operands of the Linear backward */
 int mla_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int64_t cols, mla_stream_t stream);
 /* column sums of a bf16 (rows, cols) matrix -> f32 (bias gradient of a Linear); workspace: 64 * cols doubles */
