@@ -1,5 +1,7 @@
+"""conv1 backward (bf16 gradient in): error against torch autograd on the bf16-rounded operands, time per call at 5 120 clips,
+determinism.   python scripts/conv1_bwd_check.py   (MLA_HIP_LIB=<variant built with -DMLA_CONV1_BWD_MFMA=0> for the vector-pipe kernel)"""
 import importlib, os, sys, json
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 PKG = "audio-classification-using-a-deep-cnn-combined-with-multi-level-attention_amd"
 ops = importlib.import_module(PKG + ".ops")
