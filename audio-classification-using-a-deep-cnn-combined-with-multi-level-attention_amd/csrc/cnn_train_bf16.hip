@@ -140,10 +140,18 @@ __global__ __launch_bounds__(256) void bias_slots_finish8_kernel(const double* _
 // row) offset is a multiple of 8 rows the key depends on the lane and the tap's kx only -- 8 address registers per lane, all other
 // offsets are immediates. The DMA applies the same involution on the source side (a piece = 8 rows x 8 chunks in lane order). Out-of-image halo pixels carry an out-of-range offset: the range check drops those lanes, so the
 // x-halo columns are zeroed once and the y-halo rows whenever a first / last band is staged.
+#ifndef MLA_WGRAD_COT
+#define MLA_WGRAD_COT 4
+#endif
 template <int CIN, int COUT, int H, int W>
 struct WBCfg {
-    static constexpr int WCO = CIN >= 128 ? 2 : 4, WCI = 8 / WCO;     // conv2's wgrad (64 input channels): 128 co x 64 ci
-    static constexpr int TCO = 32 * WCO, TCI = 32 * WCI;              // workgroup tile
+    // per-wave tile: COT x CIT 16-channel tiles x 9 taps (COT * CIT * 9 = 36 accumulator tiles). 4 x 1 (64 co x 16 ci) instead of
+    // 2 x 2: a dZ fragment then feeds 9 MFMAs and an input fragment 4 (2 x 2: 18 and 2), i.e. 26 instead of 40 transposing LDS
+    // reads per 36 MFMAs -- at 2 x 2 the eight waves asked the LDS array for ~139 B/clk, more than its 128
+    static constexpr int COT = MLA_WGRAD_COT, CIT = 4 / COT;
+    static constexpr int TCO = CIN >= 128 ? 64 : 128, TCI = CIN >= 128 ? 128 : 64;     // workgroup tile (conv2's wgrad, 64 input channels: 128 co x 64 ci)
+    static constexpr int WCO = TCO / (16 * COT), WCI = TCI / (16 * CIT);
+    static_assert(WCO * WCI == 8, "eight waves");
     static constexpr int CBZ = TCO / 64, CBA = TCI / 64;              // 64-channel blocks per image
     static constexpr int TH = W == 32 ? 4 : (W == 16 ? 8 : 12);        // image rows per staged band
     static constexpr int KSTEPS = TH * W / 32;                         // 32 pixels per MFMA k-step
@@ -187,14 +195,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_kernel(const bf16_t* __rest
     auto sh_x = [](int h) { return W == 32 ? 16 * h : 0; };
     // this wave's 32 co = 16-channel tiles 2 wr, 2 wr + 1 of the workgroup tile (ci: 2 wc, 2 wc + 1): 64-channel block and 32-byte slot
     // of each. Per-lane byte offsets of the transposing reads; everything that depends on (k-step, half, ky) is a multiple of 8 rows.
-    int zbase[2], abase[3][2];
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {
-        const int tile = 2 * wr + i, chunk = 2 * (tile & 3) + (p4 >> 1), key = (lx >> 1) & 3;
+    int zbase[C::COT], abase[3][C::CIT];
+    _Pragma("unroll") for (int i = 0; i < C::COT; ++i) {
+        const int tile = C::COT * wr + i, chunk = 2 * (tile & 3) + (p4 >> 1), key = (lx >> 1) & 3;
         zbase[i] = (tile >> 2) * C::Z_PIX * 128 + (ly * W + lx) * 128 + 16 * (chunk ^ (key << 1)) + 8 * (p4 & 1);
     }
     _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {
-            const int tile = 2 * wc + j, chunk = 2 * (tile & 3) + (p4 >> 1), key = ((lx + kx) >> 1) & 3;
+        _Pragma("unroll") for (int j = 0; j < C::CIT; ++j) {
+            const int tile = C::CIT * wc + j, chunk = 2 * (tile & 3) + (p4 >> 1), key = ((lx + kx) >> 1) & 3;
             abase[kx][j] = (tile >> 2) * C::A_PIX * 128 + (ly * C::PWP + lx + kx) * 128 + 16 * (chunk ^ (key << 1)) + 8 * (p4 & 1);
         }
 
@@ -239,9 +247,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_kernel(const bf16_t* __rest
         }
     };
 
-    f32x4 acc[2][2][9];
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)
+    f32x4 acc[C::COT][C::CIT][9];
+    _Pragma("unroll") for (int i = 0; i < C::COT; ++i)
+        _Pragma("unroll") for (int j = 0; j < C::CIT; ++j)
             _Pragma("unroll") for (int k = 0; k < 9; ++k) acc[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // zero both patch images once: the x-halo columns (and, for single-band shapes, the y-halo rows) are never written by the DMA
@@ -268,25 +276,27 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_kernel(const bf16_t* __rest
         // offset is an immediate but hipcc keeps more addresses live (spills at W = 32 and for 512 -> 512: 611 -> 941 and
         // 981 -> 1200 TFLOP/s when NOT unrolled); the other three shapes lose 7-11 % without it
         auto kstep = [&](int s) {
-            bf16x8 za[2];
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) {
+            bf16x8 za[C::COT];
+            _Pragma("unroll") for (int i = 0; i < C::COT; ++i) {
                 s16x4 part[2];
                 _Pragma("unroll") for (int h = 0; h < 2; ++h)
                     part[h] = tr_read(sZ + zbase[i] + (sh_y(s, h) * W + sh_x(h)) * 128);
                 za[i] = frag_of(part[0], part[1]);
             }
+            // (reading every fragment of a k-step first and issuing its 36 MFMAs as one burst, as conv.hip does, measured 7-8 % SLOWER on the
+            // unrolled shapes: hipcc's own interleaving across the unrolled k-steps is the better schedule here)
             _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {
-                bf16x8 ab[3][2];
+                bf16x8 ab[3][C::CIT];
                 _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)
-                    _Pragma("unroll") for (int j = 0; j < 2; ++j) {
+                    _Pragma("unroll") for (int j = 0; j < C::CIT; ++j) {
                         s16x4 part[2];
                         _Pragma("unroll") for (int h = 0; h < 2; ++h)
                             part[h] = tr_read(sA + abase[kx][j] + ((sh_y(s, h) + ky) * C::PWP + sh_x(h)) * 128);
                         ab[kx][j] = frag_of(part[0], part[1]);
                     }
                 _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)
-                    _Pragma("unroll") for (int i = 0; i < 2; ++i)
-                        _Pragma("unroll") for (int j = 0; j < 2; ++j)
+                    _Pragma("unroll") for (int i = 0; i < C::COT; ++i)
+                        _Pragma("unroll") for (int j = 0; j < C::CIT; ++j)
                             acc[i][j][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[i], ab[kx][j], acc[i][j][ky * 3 + kx], 0, 0, 0);
             }
         };
@@ -300,12 +310,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_kernel(const bf16_t* __rest
     }
     // partial[split][co][tap][ci]; C/D layout: col = lane & 15 (ci), row = 4 (lane >> 4) + reg (co)
     float* out = partial + size_t(split) * COUT * 9 * CIN;
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)
+    _Pragma("unroll") for (int i = 0; i < C::COT; ++i)
+        _Pragma("unroll") for (int j = 0; j < C::CIT; ++j)
             _Pragma("unroll") for (int k = 0; k < 9; ++k) {
                 const float v[4] = {acc[i][j][k].x, acc[i][j][k].y, acc[i][j][k].z, acc[i][j][k].w};
                 _Pragma("unroll") for (int e = 0; e < 4; ++e) {
-                    const int co = co0 + (wr * 2 + i) * 16 + 4 * q + e, ci = ci0 + (wc * 2 + j) * 16 + r;
+                    const int co = co0 + (wr * C::COT + i) * 16 + 4 * q + e, ci = ci0 + (wc * C::CIT + j) * 16 + r;
                     out[(size_t(co) * 9 + k) * CIN + ci] = v[e];
                 }
             }
