@@ -143,13 +143,16 @@ __global__ __launch_bounds__(256) void bias_slots_finish8_kernel(const double* _
 #ifndef MLA_WGRAD_COT
 #define MLA_WGRAD_COT 4
 #endif
+#ifndef MLA_WGRAD_TCO128
+#define MLA_WGRAD_TCO128 1              // workgroup tile 128 co x 64 ci for every shape (0: 64 x 128 where Cin >= 128): the haloed, pitch-padded input
+#endif                                // patch is the expensive operand to stage (1.9x its useful bytes), the dZ band is not: conv3 / conv4 +5 ... 6 %
 template <int CIN, int COUT, int H, int W>
 struct WBCfg {
     // per-wave tile: COT x CIT 16-channel tiles x 9 taps (COT * CIT * 9 = 36 accumulator tiles). 4 x 1 (64 co x 16 ci) instead of
     // 2 x 2: a dZ fragment then feeds 9 MFMAs and an input fragment 4 (2 x 2: 18 and 2), i.e. 26 instead of 40 transposing LDS
     // reads per 36 MFMAs -- at 2 x 2 the eight waves asked the LDS array for ~139 B/clk, more than its 128
     static constexpr int COT = MLA_WGRAD_COT, CIT = 4 / COT;
-    static constexpr int TCO = CIN >= 128 ? 64 : 128, TCI = CIN >= 128 ? 128 : 64;     // workgroup tile (conv2's wgrad, 64 input channels: 128 co x 64 ci)
+    static constexpr int TCO = (MLA_WGRAD_TCO128 || CIN < 128) ? 128 : 64, TCI = (MLA_WGRAD_TCO128 || CIN < 128) ? 64 : 128;     // workgroup tile
     static constexpr int WCO = TCO / (16 * COT), WCI = TCI / (16 * CIT);
     static_assert(WCO * WCI == 8, "eight waves");
     static constexpr int CBZ = TCO / 64, CBA = TCI / 64;              // 64-channel blocks per image
