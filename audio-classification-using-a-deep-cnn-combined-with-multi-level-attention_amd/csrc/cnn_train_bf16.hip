@@ -143,6 +143,9 @@ __global__ __launch_bounds__(256) void bias_slots_finish8_kernel(const double* _
 #ifndef MLA_WGRAD_COT
 #define MLA_WGRAD_COT 4
 #endif
+#ifndef MLA_WGRAD_DMA_STAGGER
+#define MLA_WGRAD_DMA_STAGGER 1
+#endif
 #ifndef MLA_WGRAD_TCO128
 #define MLA_WGRAD_TCO128 1              // workgroup tile 128 co x 64 ci for every shape (0: 64 x 128 where Cin >= 128): the haloed, pitch-padded input
 #endif                                // patch is the expensive operand to stage (1.9x its useful bytes), the dZ band is not: conv3 / conv4 +5 ... 6 %
@@ -159,6 +162,9 @@ struct WBCfg {
     static constexpr int TH = W == 32 ? 4 : (W == 16 ? 8 : 12);        // image rows per staged band
     static constexpr int KSTEPS = TH * W / 32;                         // 32 pixels per MFMA k-step
     static constexpr bool UNROLL = !(W == 32 || (CIN == 512 && COUT == 512));
+    // per shape like UNROLL: measured +7 / +1 / +4 / +7 % for conv2 / conv3 / conv4 / conv6; the 256 -> 512 shape spills 24 registers with it
+    // (and a spill reload waits for every outstanding DMA: -59 %)
+    static constexpr bool DMA_STAGGER = MLA_WGRAD_DMA_STAGGER && !(CIN == 256 && COUT == 512);
     static constexpr int BANDS = H / TH;
     static constexpr int PW = W + 2, PH = TH + 2;
     static constexpr int PWP = (PW + 7) / 8 * 8;                       // patch row pitch in pixel rows: a multiple of 8, so that the
@@ -269,10 +275,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_kernel(const bf16_t* __rest
     __syncthreads();
     for (int it = 0; it < n_items; ++it) {
         const int buf = it & 1;
-        if (it + 1 < n_items) {
-            const int ni = it + 1;
-            stage(split + (ni / C::BANDS) * splits, ni % C::BANDS, buf ^ 1);     // lands under this item's MFMAs
-        }
+        // the next item lands under this item's MFMAs. Issuing an item's ~10 DMA pieces stalls a wave for up to a thousand cycles
+        // (gemm.hip's stamps); with MLA_WGRAD_DMA_STAGGER the two waves of a SIMD do not do that at the same time: waves 0-3 issue in
+        // front of the first k-step, waves 4-7 behind it
+        const int ni = it + 1;
+        const bool more = ni < n_items;
+        const bool issue_late = C::DMA_STAGGER && __builtin_amdgcn_readfirstlane(wave) >= 4;
+        if (more && !issue_late) stage(split + (ni / C::BANDS) * splits, ni % C::BANDS, buf ^ 1);
         const char* sZ = smem + buf * C::BUF_BYTES;
         const char* sA = sZ + C::Z_BYTES;
         // k-step body. Whether the loop over the band's k-steps is unrolled is a per-shape choice (C::UNROLL): unrolled, every LDS
@@ -303,10 +312,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_kernel(const bf16_t* __rest
                             acc[i][j][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[i], ab[kx][j], acc[i][j][ky * 3 + kx], 0, 0, 0);
             }
         };
+        constexpr int S0 = C::DMA_STAGGER ? 1 : 0;             // the first k-step is peeled only where the late issue goes behind it
+        if constexpr (C::DMA_STAGGER) {
+            kstep(0);
+            if (more && issue_late) stage(split + (ni / C::BANDS) * splits, ni % C::BANDS, buf ^ 1);
+        }
         if constexpr (C::UNROLL) {
-            _Pragma("unroll") for (int s = 0; s < C::KSTEPS; ++s) kstep(s);
+            _Pragma("unroll") for (int s = S0; s < C::KSTEPS; ++s) kstep(s);
         } else {
-            _Pragma("unroll 1") for (int s = 0; s < C::KSTEPS; ++s) kstep(s);
+            _Pragma("unroll 1") for (int s = S0; s < C::KSTEPS; ++s) kstep(s);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next item has landed before the barrier publishes it
         __syncthreads();                                       // ... and everybody is done reading this one
