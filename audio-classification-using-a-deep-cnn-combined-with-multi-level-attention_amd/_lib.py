@@ -101,6 +101,8 @@ def lib():
         L.mla_relu_pool_bwd_bf16.argtypes = [vp, ci, vp, ci, vp, i64, ci, ci, ci, ci, vp, vp, vp]
         L.mla_conv_wgrad_bf16.argtypes = [vp, vp, i64, ci, ci, ci, ci, vp, i64, vp, vp]
         L.mla_conv1_bwd_bf16.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp]
+        L.mla_conv3x3_train_codes.argtypes = [vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, ci, vp]
+        L.mla_pool_bwd_codes_bf16.argtypes = [vp, vp, vp, i64, ci, ci, ci, vp, vp, vp]
         L.mla_conv1_bwd_workspace_floats.argtypes = []
         L.mla_conv1_bwd_workspace_floats.restype = i64
         L.mla_transpose_bf16.argtypes = [vp, i64, vp, i64, i64, i64, vp]

@@ -7,9 +7,10 @@ train.py:96-97 made the CNN trainable). NHWC. Two arithmetic modes, chosen by th
   produced in f32 and applied to the f32 master parameters (mixed precision; bf16 has f32's exponent range, so no
   loss scaling). The bf16 weight copies are re-derived from the masters after every Adam step.
 
-Forward keeps, per conv layer, its input and its pre-pool post-ReLU output; the pooled layers
-run mla_conv3x3_train, which writes the pre-pool activation AND its max-pool, so that the pool/ReLU backward can route gradients to
-the first maximum of each window. Backward per layer: mla_relu_pool_bwd -> dZ (+ db on the way); mla_conv_wgrad
+Forward keeps, per conv layer, its input and what the pool / ReLU backward needs of its output: the un-pooled layers their
+post-ReLU output, the pooled layers one byte per pooled element in bf16 mode (mla_conv3x3_train_codes: the window position of the
+first maximum, or "ReLU off") and the whole pre-pool activation in f32 mode (mla_conv3x3_train), so that the backward can route
+gradients to the first maximum of each window. Backward per layer: mla_relu_pool_bwd -> dZ (+ db on the way); mla_conv_wgrad
 (dW); mla_conv3x3 with flipped/transposed weights (dgrad). The three Linear
 layers use the MFMA GEMM on transposed copies, as the MLA head does."""
 
@@ -43,7 +44,9 @@ def forward(cnn_model, x, precision="f32"):
     for layer in range(2, 7):
         cin, cout, H, W_, pooled = GEOM[layer]
         c = convs[layer - 1]
-        if pooled:              # one kernel writes the kept pre-pool activation and the pooled one
+        if pooled and dtype == torch.bfloat16:      # one kernel writes the pooled activation and one byte per pooled element (window
+            a, nxt = ops.conv3x3_train_codes(cur, packed[layer - 2], c.bias.detach(), cout)      # position of the maximum | ReLU off)
+        elif pooled:            # exact-f32 mode: one kernel writes the kept pre-pool activation and the pooled one
             a, nxt = ops.conv3x3_train(cur, packed[layer - 2], c.bias.detach(), cout)
         else:
             a = nxt = ops.conv3x3(cur, packed[layer - 2], c.bias.detach(), cout, pool=False, act=True)
@@ -122,7 +125,10 @@ def backward(cnn_model, tape, d_out, grads, prefix, after_layer=None):
         cin, cout, H, W_, pooled = GEOM[layer]
         a_in, a = tape["layers"][layer]
         key = conv_keys[pos]
-        dz = ops.relu_pool_bwd(a, d.contiguous(), pool=pooled, db=g(key + "bias"))     # bias gradient summed on the way
+        if a.dtype == torch.uint8:                                           # window codes of the training forward (bf16 mode)
+            dz = ops.pool_bwd_codes(a, d.contiguous(), db=g(key + "bias"))
+        else:
+            dz = ops.relu_pool_bwd(a, d.contiguous(), pool=pooled, db=g(key + "bias"))     # bias gradient summed on the way
         if g(key + "weight") is not None:
             ops.conv_wgrad(dz, a_in, g(key + "weight"))
         done(pos)

@@ -129,6 +129,43 @@ __global__ __launch_bounds__(256) void bias_slots_finish8_kernel(const double* _
     if (threadIdx.x == 0) db[c] = float(part[0]);
 }
 
+// Pool / ReLU backward from the window CODES the training forward wrote (mla_conv3x3_train_codes: one byte per pooled element, the
+// position of the first maximum or 4 where the ReLU is off) instead of the pre-pool activation: 1 + 2 bytes read per pooled element
+// instead of 8 + 2, same dZ. One lane per (n, yo, xo, 8 channels); bias slots as relu_pool_bwd_bf16_kernel.
+__global__ __launch_bounds__(256) void pool_bwd_codes_bf16_kernel(const uint8_t* __restrict__ codes, const bf16_t* __restrict__ d_out,
+                                                                  bf16_t* __restrict__ dz, int64_t total8, int H, int W, int C,
+                                                                  double* __restrict__ slots) {
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int c8 = C / 8, WO = W / 2, HO = H / 2;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < total8; i += int64_t(gridDim.x) * 256) {
+        float d[8], g[8];
+        load8(d_out + i * 8, d);
+        const u32x2 cw = *reinterpret_cast<const u32x2*>(codes + i * 8);
+        const int c = int(i % c8);
+        int64_t r = i / c8;
+        const int xo = int(r % WO); r /= WO;
+        const int yo = int(r % HO);
+        const int64_t n = r / HO;
+        const int64_t base = ((n * H + 2 * yo) * W + 2 * xo) * C + c * 8;
+        const int64_t off[4] = {0, C, int64_t(W) * C, int64_t(W) * C + C};
+        uint32_t code[8];
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) {
+            code[k] = (cw[k >> 2] >> (8 * (k & 3))) & 0xffu;
+            g[k] = code[k] < 4u ? d[k] : 0.f;
+            acc[k] += double(g[k]);
+        }
+        _Pragma("unroll") for (int w = 0; w < 4; ++w) {
+            float o[8];
+            _Pragma("unroll") for (int k = 0; k < 8; ++k) o[k] = code[k] == uint32_t(w) ? g[k] : 0.f;
+            store8(dz + base + off[w], o);
+        }
+    }
+    if (slots) {
+        double* s = slots + (int64_t(blockIdx.x) * 256 + threadIdx.x) * 8;
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) s[k] = acc[k];
+    }
+}
+
 // ------------------------------------------------------------------------------------ wgrad ---
 // One persistent 8-wave workgroup per CU; waves as WCO x WCI, each 32 co x 32 ci x 9 taps (144 accumulator registers); workgroup
 // tile (32 WCO) co x (32 WCI) ci. Work items = (image, band of TH rows) of this workgroup's image split. Per item the dZ band and
@@ -723,6 +760,26 @@ extern "C" int mla_relu_pool_bwd_bf16(const void* a, int a_dtype, const void* d_
         hipLaunchKernelGGL((relu_pool_bwd_bf16_kernel<float, float>), dim3(kBiasGrid8), dim3(256), 0, s, static_cast<const float*>(a),
                            static_cast<const float*>(d_out), static_cast<bf16_t*>(dz), total8, H, W, C, pool, slots);
     MLA_LAUNCH_OK("relu_pool_bwd_bf16");
+    if (db) {
+        hipLaunchKernelGGL(bias_slots_finish8_kernel, dim3(unsigned(C)), dim3(256), 0, s, slots, int64_t(kBiasGrid8) * 256, C, db);
+        MLA_LAUNCH_OK("bias_slots_finish8");
+    }
+    return MLA_OK;
+}
+
+extern "C" int mla_pool_bwd_codes_bf16(const void* codes, const void* d_pooled, void* dz, int64_t n, int H, int W, int C, void* workspace,
+                                       float* db, mla_stream_t stream) {
+    MLA_REQUIRE(codes && d_pooled && dz && n > 0, MLA_E_ARG, "bad pool_bwd_codes arguments");
+    MLA_REQUIRE(C > 0 && C % 8 == 0 && (kBiasGrid8 * 256) % (C / 8) == 0, MLA_E_SHAPE, "channel count %d", C);
+    MLA_REQUIRE(H % 2 == 0 && W % 2 == 0, MLA_E_SHAPE, "pooling needs even H, W");
+    MLA_REQUIRE(!db || workspace, MLA_E_ARG, "the bias gradient needs the workspace");
+    MLA_REQUIRE(mla::aligned(codes, 8) && mla::aligned(d_pooled, 16) && mla::aligned(dz, 16), MLA_E_ARG, "buffers must be 16-byte aligned (codes: 8)");
+    const int64_t total8 = n * (H / 2) * (W / 2) * C / 8;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* slots = db ? static_cast<double*>(workspace) : nullptr;
+    hipLaunchKernelGGL(pool_bwd_codes_bf16_kernel, dim3(kBiasGrid8), dim3(256), 0, s, static_cast<const uint8_t*>(codes),
+                       static_cast<const bf16_t*>(d_pooled), static_cast<bf16_t*>(dz), total8, H, W, C, slots);
+    MLA_LAUNCH_OK("pool_bwd_codes_bf16");
     if (db) {
         hipLaunchKernelGGL(bias_slots_finish8_kernel, dim3(unsigned(C)), dim3(256), 0, s, slots, int64_t(kBiasGrid8) * 256, C, db);
         MLA_LAUNCH_OK("bias_slots_finish8");

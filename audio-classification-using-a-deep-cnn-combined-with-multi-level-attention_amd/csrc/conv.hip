@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                                                                const typename C::elem* __restrict__ wgt,
                                                                const float* __restrict__ bias,
                                                                typename C::elem* __restrict__ out, int n_img, int n_tiles,
-                                                               typename C::elem* __restrict__ prepool) {
+                                                               typename C::elem* __restrict__ prepool, uint8_t* __restrict__ codes) {
     using T = typename C::elem;
     constexpr int PER = Elem<T>::kPerChunk;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -543,6 +543,39 @@ __global__ __launch_bounds__(kThreads, C::MIN_WAVES) void conv3x3_kernel(const t
                         T* o = out + ((size_t(img) * C::HO + yo) * C::WO + xo) * C::COUT_MEM + nb;
                         store_px<C>(o, p0);
                         store_px<C>(o + C::COUT_MEM, p1);
+                    }
+                    // training forward, compact form (mla_conv3x3_train_codes): instead of the pre-pool activation (8 bytes per pooled
+                    // element in bf16) one BYTE -- the window position of the first maximum in MaxPool2d's order (0,0) (0,1) (1,0) (1,1),
+                    // or 4 where the ReLU is off -- which is all the pool / ReLU backward needs from it
+                    if constexpr (!C::SPLIT) {
+                        if (codes && img < n_img) {
+                            auto code_of = [](float a0, float a1, float a2, float a3) -> uint32_t {
+                                const bool m1 = a1 > a0;
+                                const float b1 = m1 ? a1 : a0;
+                                const bool m2 = a2 > b1;
+                                const float b2 = m2 ? a2 : b1;
+                                const bool m3 = a3 > b2;
+                                const float b3 = m3 ? a3 : b2;
+                                return b3 > 0.f ? (m3 ? 3u : (m2 ? 2u : (m1 ? 1u : 0u))) : 4u;
+                            };
+                            uint32_t c0 = 0u, c1 = 0u;
+                            _Pragma("unroll") for (int j = 0; j < C::NS; ++j) {
+                                const f32x4 u = acc[2 * ip][j], d = acc[2 * ip + 1][j];
+                                c0 |= code_of(u.x, u.y, d.x, d.y) << (8 * j);
+                                c1 |= code_of(u.z, u.w, d.z, d.w) << (8 * j);
+                            }
+                            uint8_t* cp = codes + ((size_t(img) * C::HO + yo) * C::WO + xo) * C::COUT + nb;     // the lane's NS consecutive channels
+                            if constexpr (C::NS == 4) {
+                                *reinterpret_cast<uint32_t*>(cp) = c0;
+                                *reinterpret_cast<uint32_t*>(cp + C::COUT) = c1;
+                            } else if constexpr (C::NS == 2) {
+                                *reinterpret_cast<uint16_t*>(cp) = uint16_t(c0);
+                                *reinterpret_cast<uint16_t*>(cp + C::COUT) = uint16_t(c1);
+                            } else {
+                                cp[0] = uint8_t(c0);
+                                cp[C::COUT] = uint8_t(c1);
+                            }
+                        }
                     }
                 }
             } else {
@@ -881,7 +914,8 @@ inline bool wide_tiles() {
 }
 
 template <typename C>
-int launch_conv(const void* in, const void* w, const float* bias, void* out, int64_t n_img, hipStream_t s, void* prepool = nullptr) {
+int launch_conv(const void* in, const void* w, const float* bias, void* out, int64_t n_img, hipStream_t s, void* prepool = nullptr,
+                uint8_t* codes = nullptr) {
     using T = typename C::elem;
     auto kern = conv3x3_kernel<C>;
     MLA_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -898,7 +932,7 @@ int launch_conv(const void* in, const void* w, const float* bias, void* out, int
     if (gx < C::TILES_Y) gx = C::TILES_Y;
     if (gx > tiles || !C::PERSIST) gx = tiles;
     hipLaunchKernelGGL(kern, dim3(unsigned(gx), n_tiles_n), dim3(kThreads), C::LDS_BYTES, s,
-                       static_cast<const T*>(in), static_cast<const T*>(w), bias, static_cast<T*>(out), int(n_img), int(tiles), static_cast<T*>(prepool));
+                       static_cast<const T*>(in), static_cast<const T*>(w), bias, static_cast<T*>(out), int(n_img), int(tiles), static_cast<T*>(prepool), codes);
     MLA_LAUNCH_OK("conv3x3_kernel");
     return MLA_OK;
 }
@@ -962,17 +996,17 @@ __global__ void repack_dgrad_kernel(const float* __restrict__ w, float* __restri
 // fused pool (training keeps the pre-pool activations) and the five dgrad shapes; f32 (exact) and bf16
 template <typename T>
 int conv_generic(const void* in, const void* w, const float* bias, void* out, int64_t n, int H, int W, int cin, int cout,
-                 bool pool, bool act, hipStream_t s, void* prepool = nullptr) {
+                 bool pool, bool act, hipStream_t s, void* prepool = nullptr, uint8_t* codes = nullptr) {
 #define MLA_CONV_CASE(CI, CO, HH, WW, PO, NS_, AC)                                                             \
     if (cin == CI && cout == CO && H == HH && W == WW && pool == PO && act == AC)                              \
-        return launch_conv<Cfg<T, CI, CO, HH, WW, PO, NS_, AC>>(in, w, bias, out, n, s, prepool);
+        return launch_conv<Cfg<T, CI, CO, HH, WW, PO, NS_, AC>>(in, w, bias, out, n, s, prepool, codes);
     // Cout >= 128: bf16 runs the tall tile (384 pixels x 128 channels, NS = 4), f32 the wide one with NS_ as given
 #define MLA_CONV_CASE_TALL(CI, CO, HH, WW, PO, NS_, AC)                                                        \
     if (cin == CI && cout == CO && H == HH && W == WW && pool == PO && act == AC) {                            \
         if constexpr (sizeof(T) == 2 && MLA_CONV_TALL)                                                         \
             if (!wide_tiles())                                                                                 \
-                return launch_conv<Cfg<T, CI, CO, HH, WW, PO, 4, AC, false, 4>>(in, w, bias, out, n, s, prepool);  \
-        return launch_conv<Cfg<T, CI, CO, HH, WW, PO, NS_, AC>>(in, w, bias, out, n, s, prepool);              \
+                return launch_conv<Cfg<T, CI, CO, HH, WW, PO, 4, AC, false, 4>>(in, w, bias, out, n, s, prepool, codes);  \
+        return launch_conv<Cfg<T, CI, CO, HH, WW, PO, NS_, AC>>(in, w, bias, out, n, s, prepool, codes);              \
     }
 #if MLA_CONV_TALL >= 2
 #define MLA_CONV_CASE_TALL8 MLA_CONV_CASE_TALL
@@ -1028,6 +1062,19 @@ extern "C" int mla_conv3x3_train(const void* in, const void* w_packed, const flo
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == MLA_BF16) return conv_generic<bf16_t>(in, w_packed, bias, out_pooled, n, H, W, cin, cout, true, true, s, out_prepool);
     return conv_generic<float>(in, w_packed, bias, out_pooled, n, H, W, cin, cout, true, true, s, out_prepool);
+}
+
+extern "C" int mla_conv3x3_train_codes(const void* in, const void* w_packed, const float* bias, void* out_codes, void* out_pooled, int64_t n,
+                                       int H, int W, int cin, int cout, int dtype, mla_stream_t stream) {
+    MLA_REQUIRE(n >= 0, MLA_E_ARG, "n %lld", (long long)n);
+    if (n == 0) return MLA_OK;
+    MLA_REQUIRE(in && w_packed && bias && out_codes && out_pooled, MLA_E_ARG, "null conv buffers");
+    MLA_REQUIRE(mla::aligned(in, 16) && mla::aligned(w_packed, 16) && mla::aligned(out_codes, 4), MLA_E_ARG, "conv buffers must be 16-byte aligned (codes: 4)");
+    MLA_REQUIRE(dtype == MLA_F32 || dtype == MLA_BF16, MLA_E_DTYPE, "conv3x3_train_codes dtype %d", dtype);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint8_t* codes = static_cast<uint8_t*>(out_codes);
+    if (dtype == MLA_BF16) return conv_generic<bf16_t>(in, w_packed, bias, out_pooled, n, H, W, cin, cout, true, true, s, nullptr, codes);
+    return conv_generic<float>(in, w_packed, bias, out_pooled, n, H, W, cin, cout, true, true, s, nullptr, codes);
 }
 
 extern "C" int mla_conv_repack_dgrad(const float* w_oihw, int64_t cout, int64_t cin, float* out, mla_stream_t stream) {

@@ -493,6 +493,34 @@ def conv3x3_train(x, w_packed, b, cout):
     return a, pooled
 
 
+def conv3x3_train_codes(x, w_packed, b, cout):
+    """Training forward of a pooled layer, compact form: (window codes uint8 (n, H/2, W/2, cout), pooled activation). A code is the
+    position 0..3 of the first maximum of the 2x2 window (MaxPool2d's order), or 4 where the ReLU is off -- one byte instead of the
+    four pre-pool activations (8 bytes in bf16) that conv3x3_train keeps for the backward."""
+    _chk(x); _chk(w_packed, x.dtype)
+    n, H, W_, cin = x.shape
+    codes = torch.empty((n, H // 2, W_ // 2, cout), dtype=torch.uint8, device=x.device)
+    pooled = torch.empty((n, H // 2, W_ // 2, cout), dtype=x.dtype, device=x.device)
+    _lib.check(_timed("conv3x3_%d_%d" % (cin, cout), _lib.lib().mla_conv3x3_train_codes, _p(x), _p(w_packed), _p(b), _p(codes), _p(pooled),
+                      n, H, W_, cin, cout, DT[x.dtype], _lib.stream_ptr()))
+    return codes, pooled
+
+
+def pool_bwd_codes(codes, d_out, db=None):
+    """dZ (n, H, W, C) bf16 at the pre-pool resolution from the window codes and the pooled gradient; db: bias gradient on the way."""
+    assert codes.dtype == torch.uint8 and codes.is_cuda and codes.is_contiguous()
+    _chk(d_out, torch.bfloat16)
+    n, HO, WO, C = codes.shape
+    assert tuple(d_out.shape) == tuple(codes.shape)
+    dz = torch.empty((n, 2 * HO, 2 * WO, C), dtype=torch.bfloat16, device=codes.device)
+    key = "biasws16/" + str(codes.device)
+    if key not in _ws:
+        _ws[key] = torch.empty(int(_lib.lib().mla_relu_pool_bwd_bf16_workspace_bytes()) // 8, dtype=torch.float64, device=codes.device)
+    _lib.check(_timed("relu_pool_bwd", _lib.lib().mla_pool_bwd_codes_bf16, _p(codes), _p(d_out), _p(dz), n, 2 * HO, 2 * WO, C, _p(_ws[key]),
+                      _p(db), _lib.stream_ptr()))
+    return dz
+
+
 def repack_dgrad(w, dtype=torch.float32):
     """(Cout, Cin, 3, 3) f32 -> (Cin, 9, Cout) flipped, in `dtype`: weights of the transposed convolution."""
     _chk(w, torch.float32)

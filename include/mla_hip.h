@@ -319,6 +319,14 @@ int mla_conv_wgrad_bf16(const void* dz, const void* a_in, int64_t n, int H, int 
                         int64_t workspace_floats, float* dw_oihw, mla_stream_t stream);
 /* conv1 backward with the incoming gradient in bf16: recompute and weight-gradient products on the matrix cores (patch GEMM, see
  * cnn_train_bf16.hip). workspace: mla_conv1_bwd_workspace_floats() floats (also enough for mla_conv1_bwd). */
+/* Training forward of a pooled layer, compact form: instead of the pre-pool activation of mla_conv3x3_train, one BYTE per pooled element
+ * (N, H/2, W/2, Cout) -- the window position 0..3 of the first maximum in nn.MaxPool2d's order, or 4 where the ReLU is off -- which is all
+ * autograd's backward of `MaxPool2d(ReLU(conv))` (vggish.py:108-118 under train.py:137) needs from that tensor; and the backward that
+ * consumes it: dZ (N, H, W, C) bf16 from the codes and the pooled gradient, db on the way (workspace as mla_relu_pool_bwd_bf16). */
+int mla_conv3x3_train_codes(const void* in, const void* w_packed, const float* bias, void* out_codes_u8, void* out_pooled, int64_t n,
+                            int H, int W, int cin, int cout, int dtype, mla_stream_t stream);
+int mla_pool_bwd_codes_bf16(const void* codes_u8, const void* d_pooled_bf16, void* dz_bf16, int64_t n, int H, int W, int C, void* workspace,
+                            float* db, mla_stream_t stream);
 int mla_conv1_bwd_bf16(const float* x, const float* w, const float* bias, const void* d_pooled_bf16, int64_t n, float* workspace,
                        float* dw, float* db, mla_stream_t stream);
 int64_t mla_conv1_bwd_workspace_floats(void);

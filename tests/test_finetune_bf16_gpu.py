@@ -255,3 +255,34 @@ def test_conv1_backward_on_the_matrix_cores_matches_autograd(n, tol):
     db2 = torch.empty_like(db)
     ops.conv1_bwd(x.cuda(), w.cuda(), b.cuda(), d.cuda(), dw2, db2)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(64, 128, 48, 32), (256, 256, 24, 16), (512, 512, 12, 8)])
+def test_window_codes_route_gradients_like_the_prepool_activation(shape):
+    """bf16 training forward of the pooled layers keeps ONE byte per pooled element (mla_conv3x3_train_codes: position of the window's
+    first maximum, or "ReLU off") instead of the pre-pool activation (mla_conv3x3_train). Both forms must give the same pooled output
+    bit for bit, the same gradient mass per window and the same bias gradient; the routed position may differ only where two f32
+    pre-activations of a window round to the same bf16 value (the codes compare the f32 accumulators, the activation path the stored
+    bf16 values): a fraction of a percent of the windows."""
+    ops = importlib.import_module(PKG + ".ops")
+    cin, cout, H, W_ = shape
+    n = 6
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand((n, H, W_, cin), generator=g) * 2 - 0.6).clamp_min(0).to(torch.bfloat16).cuda()
+    w = ((torch.rand((cout, cin, 3, 3), generator=g) - 0.5) * (2.0 / (9 * cin) ** 0.5)).cuda()
+    b = ((torch.rand(cout, generator=g) - 0.5) * 0.1).cuda()
+    d = (torch.rand((n, H // 2, W_ // 2, cout), generator=g) - 0.5).to(torch.bfloat16).cuda()
+    wp = ops.repack_conv_weight(w, torch.bfloat16)
+    a, pooled_a = ops.conv3x3_train(x, wp, b, cout)
+    codes, pooled_c = ops.conv3x3_train_codes(x, wp, b, cout)
+    assert codes.dtype == torch.uint8 and int(codes.max()) <= 4 and torch.equal(pooled_a.view(torch.int16), pooled_c.view(torch.int16))
+    assert torch.equal(codes == 4, pooled_c == 0)                                     # ReLU off <=> the pooled output is zero
+    db_a = torch.empty(cout, device="cuda")
+    db_c = torch.empty(cout, device="cuda")
+    dz_a = ops.relu_pool_bwd(a, d, pool=True, db=db_a)
+    dz_c = ops.pool_bwd_codes(codes, d, db=db_c)
+    win = lambda t: t.float().reshape(n, H // 2, 2, W_ // 2, 2, cout).sum(dim=(2, 4))
+    assert torch.equal(win(dz_a), win(dz_c)) and torch.equal(db_a, db_c)              # same gradient mass per window, same bias gradient
+    differ = float((dz_a != dz_c).float().mean())
+    assert differ < 5e-3, differ
