@@ -135,6 +135,8 @@ def backward(cnn_model, tape, d_out, grads, prefix, after_layer=None):
         if pos > lowest:
             wd = ops.repack_dgrad(convs[layer - 1].weight.detach().contiguous(), tape["dtype"])
             d = ops.conv3x3(dz, wd, None, cin, pool=False, act=False)
+    if lowest > 0:          # conv1 is not in the update set: `d` is still the gradient of the lowest trained layer's OUTPUT, not conv1's
+        return
     key = conv_keys[0]
     dw = g(key + "weight") if g(key + "weight") is not None else torch.empty((64, 1, 3, 3), dtype=torch.float32, device=d.device)
     db = g(key + "bias") if g(key + "bias") is not None else torch.empty(64, dtype=torch.float32, device=d.device)

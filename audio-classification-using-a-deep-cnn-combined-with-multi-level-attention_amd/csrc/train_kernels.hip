@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 // loss = inv_total * sum_b (logsumexp(x_b) - x_b[y_b]);  dx = inv_total * (softmax(x_b) - onehot(y_b))
 // one block: deterministic double-precision reduction. inv_total = 1 / (global batch).
 // A label outside [0, K) (nn.CrossEntropyLoss raises "Target out of bounds" for it) is never used as an index: the row
-// contributes nothing, the loss comes out NaN and *n_correct = -(number of such labels), which the host layer turns into
+// contributes nothing, the loss comes out NaN and n_correct[1] = the number of such labels, which the host layer turns into
 // the exception (ops.cross_entropy / train_model) without a per-step synchronisation of its own.
 __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ x, int64_t ldx,
                                                             const int64_t* __restrict__ labels, int64_t rows, int K,
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
     }
     if (threadIdx.x == 0) {
         *loss = bads[0] ? __builtin_nanf("") : float(part[0] * inv_total);
-        if (n_correct) *n_correct = bads[0] ? -bads[0] : hits[0];
+        if (n_correct) { n_correct[0] = hits[0]; n_correct[1] = bads[0]; }
     }
 }
 

@@ -164,7 +164,8 @@ def linear(a, w, b, relu=False, out_dtype=None, out=None, split_k=False):
         assert out.is_contiguous() and out.numel() == M * N and out.dtype == out_dtype
     # narrow outputs (the attention modules' 600 -> 10 fcv): a dedicated one-pass kernel instead of a nearly empty MFMA tile
     if (N <= 16 and a.dtype == torch.float32 and out_dtype == torch.float32 and not relu and not split_k and K % 4 == 0
-            and K * N * 4 <= 65536 and a.stride(0) % 4 == 0 and w.stride(0) % 4 == 0):
+            and K * N * 4 <= 65536 and a.stride(0) % 4 == 0 and w.stride(0) % 4 == 0
+            and a.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0):
         _lib.check(_timed("linear_%dx%d" % (K, N), _lib.lib().mla_linear_narrow, _p(a), a.stride(0), _p(w), w.stride(0), _p(b), _p(out), N,
                           M, N, K, _lib.stream_ptr()))
         return out
@@ -283,6 +284,12 @@ class Dist:
         comm = ctypes.c_void_p()
         _lib.check(_lib.lib().mla_comm_init_rank(ctypes.byref(comm), self.world, ctypes.c_char_p(raw), self.rank))
         self.comm = comm
+        # destroyed by close() or at interpreter exit while torch and RCCL are still loaded -- never from __del__, which may
+        # run during teardown after either is gone
+        import atexit
+        import weakref
+        ref = weakref.ref(self)
+        atexit.register(lambda: ref() is not None and ref().close())
 
     def close(self):
         if self.comm is not None:
@@ -290,11 +297,6 @@ class Dist:
             _lib.check(_lib.lib().mla_comm_destroy(self.comm))
             self.comm = None
 
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
 
     def _reduce(self, t):
         """The collective itself, whatever the world size."""
@@ -437,7 +439,8 @@ def check_labels(labels, K):
     reference's dataset never produces -- labels are class indices, dataset.py:60-75 -- and which is refused here like any other
     negative label rather than silently dropped from the mean). Host tensors are checked
     here before the upload (no device sync); for device tensors the kernel refuses to index with such a label and reports
-    it through `n_correct < 0` + a NaN loss, which `raise_on_bad_labels` turns into the same exception."""
+    it through its second counter (`hits[1]` = number of such labels) + a NaN loss, which `raise_on_bad_labels` turns into the
+    same exception. The two counters are separate so that their sum over data-parallel ranks cannot cancel."""
     if not labels.is_cuda and labels.numel():
         lo, hi = int(labels.min()), int(labels.max())
         if lo < 0 or hi >= K:
@@ -445,20 +448,21 @@ def check_labels(labels, K):
 
 
 def raise_on_bad_labels(hits):
-    """Call where the step's result is read on the host anyway (train.py:141-142): `hits` is cross_entropy's n_correct."""
-    n = int(hits)
-    if n < 0:
-        raise IndexError("Target out of bounds: %d label(s) outside [0, num_classes)." % -n)
+    """Call where the step's result is read on the host anyway (train.py:141-142): `hits` is cross_entropy's pair
+    [n_correct, n_bad_labels] (summed over the ranks by a data-parallel step). Returns n_correct."""
+    n, bad = (int(v) for v in hits.tolist())
+    if bad > 0:
+        raise IndexError("Target out of bounds: %d label(s) outside [0, num_classes)." % bad)
     return n
 
 
 def cross_entropy(scores, labels, inv_total, want_grad=True):
-    """CrossEntropyLoss(mean over the GLOBAL batch) on (B, K) scores: (loss, dscores, n_correct).
-    n_correct < 0 (and a NaN loss): -n_correct labels were outside [0, K) -- see check_labels."""
+    """CrossEntropyLoss(mean over the GLOBAL batch) on (B, K) scores: (loss, dscores, hits) with hits = int32 [n_correct,
+    n_bad]; n_bad > 0 (and a NaN loss): that many labels were outside [0, K) -- see check_labels."""
     _chk(scores, torch.float32); _chk(labels, torch.int64)
     B, K = scores.shape
     loss = torch.empty(1, dtype=torch.float32, device=scores.device)
-    hits = torch.empty(1, dtype=torch.int32, device=scores.device)
+    hits = torch.empty(2, dtype=torch.int32, device=scores.device)
     d = torch.empty_like(scores) if want_grad else None
     _lib.check(_lib.lib().mla_cross_entropy(_p(scores), scores.stride(0), _p(labels), B, K, float(inv_total), _p(loss), _p(d),
                                             K, _p(hits), _lib.stream_ptr()))

@@ -160,7 +160,8 @@ class TrainStep:
 
     def __call__(self, inputs, labels):
         """inputs (B, T, 1, 96, 64) (or whatever ``clf.input`` reshapes), labels (B,) int64.
-        Returns (loss, n_correct) as device tensors (no host sync; train.py:141-142 syncs via .item())."""
+        Returns (loss, hits) as device tensors (no host sync; train.py:141-142 syncs via .item()): hits = int32
+        [n_correct, n_labels_out_of_range] over the global batch (``ops.raise_on_bad_labels(hits)`` -> n_correct or IndexError)."""
         clf = self.clf
         for n, p, ptr in self._seated:
             if p.data_ptr() != ptr:
@@ -202,7 +203,7 @@ class TrainStep:
                 if not bucketed:
                     self.dist.all_reduce_sum(self.flat_g)
                 self.dist.all_reduce_sum(loss)
-                self.dist.all_reduce_sum(hits)             # running_corrects (train.py:142) over the global batch
+                self.dist.all_reduce_sum(hits)             # [running_corrects (train.py:142), #bad labels] over the global batch
             self.t += 1
             ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
             if self.finetune:                      # derived (repacked / bf16) weight copies are stale now
@@ -340,7 +341,9 @@ def train_model(clf, dataloaders, criterion, optimizer, num_epochs=25, patience=
         run_loss, run_hits, n = 0.0, 0, 0
         for inputs, labels in dataloaders["train"]:
             loss, hits = step(inputs.to(device).float(), labels)
-            run_loss += float(loss) * inputs.shape[0]; run_hits += ops.raise_on_bad_labels(hits); n += inputs.shape[0]
+            # under data parallelism the step returns the GLOBAL mean loss and the GLOBAL hit count (train.py:141-142 on the whole batch)
+            seen = inputs.shape[0] * (step.dist.world if step.dist.active else 1)
+            run_loss += float(loss) * seen; run_hits += ops.raise_on_bad_labels(hits); n += seen
         print("train Loss: {:.4f}, Acc: {:.4f}".format(run_loss / max(n, 1), run_hits / max(n, 1)))
         v_loss, v_acc = _evaluate(clf, dataloaders["val"], device)
         print("val Loss: {:.4f}, Acc: {:.4f}".format(v_loss, v_acc))

@@ -262,8 +262,10 @@ int mla_axpy(float a, const float* x, float* y, int64_t n, mla_stream_t stream);
 
 /* nn.CrossEntropyLoss (train.py:372) on scores x (rows, K) with int64 labels: writes
  * loss = inv_total * sum_b (logsumexp(x_b) - x_b[y_b]) and, if dx != NULL,
- * dx = inv_total * (softmax(x_b) - onehot(y_b)); n_correct (optional) = #argmax hits
- * (train.py:133). inv_total = 1 / global batch (mean reduction across all ranks). */
+ * dx = inv_total * (softmax(x_b) - onehot(y_b)); n_correct (optional, TWO ints): [0] = #argmax hits
+ * (train.py:133), [1] = #labels outside [0, K) -- those rows contribute neither loss nor gradient, and the loss is NaN
+ * when there is one (nn.CrossEntropyLoss raises; the caller does, on reading [1]). Two separate counters so that a sum
+ * over data-parallel ranks cannot cancel one against the other. inv_total = 1 / global batch (mean over all ranks). */
 int mla_cross_entropy(const float* x, int64_t ldx, const int64_t* labels, int64_t rows, int K, float inv_total,
                       float* loss, float* dx, int64_t ld_dx, int* n_correct, mla_stream_t stream);
 

@@ -39,7 +39,7 @@ def run_steps(mk, W, M, TR, always, finetune):
             for j, d in enumerate(em.dropouts):
                 d.mask = masks["mla.embedded_mappings.%d.dropouts.%d" % (lvl, j)]
         loss, h = step(x.cuda(), y.cuda())
-        losses.append(float(loss)); hits.append(int(h))
+        losses.append(float(loss)); hits.append(h.tolist())
     via = step.dist.via
     step.dist.close()
     return losses, hits, step.flat_p.clone(), via

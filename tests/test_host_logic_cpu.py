@@ -47,9 +47,12 @@ def test_label_validation_matches_cross_entropy_loss():
             torch.nn.CrossEntropyLoss()(torch.zeros(len(bad), 10), torch.tensor(bad))
     with pytest.raises(IndexError):                                         # torch's ignore_index is refused, not honoured
         ops.check_labels(torch.tensor([-100]), 10)
-    assert ops.raise_on_bad_labels(torch.tensor(7)) == 7
+    assert ops.raise_on_bad_labels(torch.tensor([7, 0])) == 7               # [n_correct, n_labels_out_of_range]
     with pytest.raises(IndexError):
-        ops.raise_on_bad_labels(torch.tensor(-2))
+        ops.raise_on_bad_labels(torch.tensor([7, 2]))
+    # summed over data-parallel ranks the two counters cannot cancel: a rank with bad labels + a rank with hits still raises
+    with pytest.raises(IndexError):
+        ops.raise_on_bad_labels(torch.tensor([0, 1]) + torch.tensor([5, 0]))
 
 
 def test_resampling_filter_is_the_restated_kaiser_best_design():

@@ -15,6 +15,14 @@ from conftest import PKG, ROOT
 
 pytestmark = pytest.mark.gpu
 
+
+def free_port():
+    """A TCP port nobody listens on right now (two test runs on one host must not share a rendezvous port)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
 NOISY = ("fc.bias", "fc.0.bias", "fc.1.bias", "fcv.bias")     # zero-gradient biases: see test_oracle_golden.py
 
 
@@ -96,7 +104,7 @@ def test_two_ranks_equal_one_rank_on_the_global_batch(tmp_path, golden):
     gradient all-reduce reproduce the single-process step. Two ranks share the test GPU (gloo)."""
     g = golden("train")
     out = str(tmp_path / "dp")
-    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_worker.py"), out, "5", "8"],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
     for p in procs:
@@ -296,7 +304,7 @@ def test_train_model_honours_the_optimizer_and_rejects_what_it_cannot_do(tmp_pat
     with pytest.raises(IndexError):
         step(torch.as_tensor(x).cuda(), yb)                                   # host labels: checked before the upload
     loss, hits = step(torch.as_tensor(x).cuda(), yb.cuda())                   # device labels: the kernel refuses to index with it
-    assert int(hits) == -1 and not bool(torch.isfinite(loss))
+    assert int(hits[1]) == 1 and not bool(torch.isfinite(loss))           # hits = [n_correct, n_labels_out_of_range]
     yb[3] = -100
     with pytest.raises(IndexError):
         importlib.import_module(PKG + ".ops").raise_on_bad_labels(step(torch.as_tensor(x).cuda(), yb.cuda())[1])
@@ -311,7 +319,7 @@ def test_rccl_branch_of_the_exchange_runs_on_one_rank():
     device buffer as the alternative. A box with one GPU can only form a one-rank group, so the collectives are forced on
     (ops.Dist(always=True)); f32 / f64 / i32 buffers and the whole TrainStep must come out bit-identical to the
     no-collective run. See tests/_nccl_worker.py. The N > 1 arithmetic is covered by the gloo tests (2 ranks == 1 rank)."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_nccl_worker.py")], env=env, stdout=subprocess.PIPE,
@@ -368,7 +376,7 @@ def test_config4_full_size_step_is_deterministic_and_shards_exactly(tmp_path, mk
             install(ens, mk.make_masks(200 + s, [2, 1], B))
             loss, hits = step(x.cuda(), y.cuda())
             losses.append(float(loss))
-            assert 0 <= int(hits) <= B
+            assert 0 <= int(hits[0]) <= B and int(hits[1]) == 0
         return losses, {k: v.detach().cpu().numpy() for k, v in ens.state_dict().items() if k.startswith("mla.")}
 
     l1, sd1 = one_process()
@@ -377,7 +385,7 @@ def test_config4_full_size_step_is_deterministic_and_shards_exactly(tmp_path, mk
     assert all(np.isfinite(l1)) and abs(l1[0] - np.log(10.0)) < 0.2              # 10 classes, untrained head
 
     out = str(tmp_path / "dp512")
-    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_worker.py"), out, str(steps), str(B), "bf16"],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
     for p in procs:
@@ -405,7 +413,7 @@ def test_two_ranks_finetune_with_bucketed_gradient_exchange(tmp_path, golden):
     the reference's 4-bag finetune run and stay bit-identical replicas, CNN biases included."""
     g = golden("train")
     out = str(tmp_path / "dpft")
-    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29523", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_worker.py"), out, "3", "4", "f32", "finetune"],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
     for p in procs:
@@ -416,3 +424,39 @@ def test_two_ranks_finetune_with_bucketed_gradient_exchange(tmp_path, golden):
     assert any(k.startswith("cnn.") for k in r0.files)
     for k in r0.files:
         np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_partial_cnn_update_set_whose_lowest_layer_is_conv2(mk, W, precision):
+    """The optimizer holds conv2 (features.3) and everything above it but NOT conv1 (features.0): the backward pass must stop after
+    conv2's weight gradient -- no input gradient of conv2, no conv1 backward (which would read conv2's OUTPUT gradient, half the
+    size it expects, as if it were conv1's). Gradients of the held tensors equal the full-finetune run's bit for bit (same kernels,
+    same order), and the conv1 backward kernel is never launched."""
+    TR = importlib.import_module(PKG + ".train")
+    M = importlib.import_module(PKG + ".model")
+    ops = importlib.import_module(PKG + ".ops")
+    x, y = mk.synth_bags(100, 4)
+
+    def run(hold):
+        ens = build(mk, W)
+        ens.set_precision(precision)
+        M.set_requires_grad(ens, True)
+        params = [p for n, p in ens.named_parameters() if hold(n)]
+        step = TR.TrainStep(ens, lr=1e-3, params=params)
+        install(ens, mk.make_masks(200, [2, 1], 4))
+        ops.profile = []
+        loss, hits = step(x.cuda(), y.cuda())
+        torch.cuda.synchronize()
+        names, ops.profile = [n for n, _, _ in ops.profile], None
+        return float(loss), {k: v.clone() for k, v in step.grads.items()}, names
+
+    loss_full, g_full, names_full = run(lambda n: True)
+    loss_part, g_part, names_part = run(lambda n: "features.0." not in n)
+    assert "conv1_bwd" in names_full and "conv1_bwd" not in names_part
+    assert names_full.count("wgrad_64_128") == 1 and names_part.count("wgrad_64_128") == 1
+    # conv2's input gradient (the 128 -> 64 transposed convolution) is only needed by conv1
+    assert "conv3x3_128_64" in names_full and "conv3x3_128_64" not in names_part
+    assert loss_full == loss_part
+    assert set(g_part) == {k for k in g_full if "features.0." not in k}
+    for k, v in g_part.items():
+        assert torch.equal(v, g_full[k]), k
