@@ -15,7 +15,7 @@ from typing import Dict, List, Union
 import torch
 from torch import nn
 
-from . import mla_train, ops
+from . import differentiable, mla_train, ops
 from .params import *  # noqa: F401,F403  (T, H, K, DR, M_VGGISH, M_VGGISH_JB, S_VGGISH_SHAPE: model.py:9)
 from .torchvggish.vggish import Linear, VGGish
 
@@ -210,6 +210,8 @@ class CNN(nn.Module):
     def forward(self, x):
         x = self.cnn_model(x)
         if x.dtype == torch.bfloat16:      # bf16 bottlenecks (just_bottlenecks=True) feed the f32 head
+            if x.requires_grad:
+                return differentiable.CastFn.apply(x)
             x = ops.merge_split(x.contiguous(), 512) if self.precision == "bf16x3" else ops.to_f32(x.contiguous())
         return x
 
@@ -272,6 +274,11 @@ class MultiLevelAttention(nn.Module):
         self.norm = BatchNorm1d(K)
 
     def forward(self, x):
+        if self.training and differentiable.wants_grad(self, x):
+            # train.py:124-138 on the drop-in: outputs = clf(inputs); loss.backward() -- the head's HIP backward runs behind autograd.
+            # (eval mode with gradients enabled is not differentiable here: the reference's loop evaluates under
+            # torch.set_grad_enabled(False), train.py:128.)
+            return differentiable.HeadFn.apply(self, x.float(), *self.parameters())
         return mla_train.mla_apply(self, x)
 
 

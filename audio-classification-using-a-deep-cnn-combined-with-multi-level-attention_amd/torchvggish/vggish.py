@@ -102,6 +102,12 @@ class VGGFeatures(nn.Sequential):
         return h
 
     def forward(self, x):
+        from .. import differentiable as D
+        if D.wants_grad(self):
+            # a conv parameter requires grad and autograd is recording (the reference's loop, train.py:124-138, after
+            # cnn_trainable=True / set_requires_grad): training forward with a tape, HIP backward kernels behind loss.backward()
+            params = [t for i in (0, 3, 6, 8, 11, 13) for t in (self[i].weight, self[i].bias)]
+            return D.FeaturesFn.apply(self, D.grad_precision(self.precision), x, *params).permute(0, 3, 1, 2)
         return self.forward_nhwc(x, _DTYPES[self.precision]).permute(0, 3, 1, 2)
 
 
@@ -135,6 +141,10 @@ class VGGEmbeddings(nn.Sequential):
     def forward(self, x):
         dtype = _DTYPES[self.precision]
         fcs = self._fcs
+        from .. import differentiable as D
+        if D.wants_grad(self, x):
+            assert x.dtype == D.grad_precision(self.precision) and x.is_contiguous(), "embeddings input must come from VGGFeatures in the same precision"
+            return D.EmbeddingsFn.apply(self, dtype, x, *[t for f in fcs for t in (f.weight, f.bias)])
         if self.precision == "bf16x3":
             # the conv stack's flatten is pixel-major with [hi(512) | lo(512)] per pixel; later layers have one plane pair
             segs = [512, fcs[1].in_features, fcs[2].in_features]
