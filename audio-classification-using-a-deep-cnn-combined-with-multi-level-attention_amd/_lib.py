@@ -115,6 +115,7 @@ def lib():
         L.mla_comm_unique_id.argtypes = [vp]
         L.mla_comm_init_rank.argtypes = [ctypes.POINTER(vp), ci, vp, ci]
         L.mla_comm_destroy.argtypes = [vp]
+        L.mla_comm_count.argtypes = [vp, ctypes.POINTER(ci)]
         L.mla_comm_library_origin.restype = ctypes.c_char_p
         L.mla_allreduce_flat.argtypes = [vp, i64, ci, vp, vp]
         _lib = L

@@ -26,6 +26,7 @@ struct Api {
     int (*GetUniqueId)(UniqueId*) = nullptr;
     int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
+    int (*CommCount)(Comm, int*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     const char* origin = "";
@@ -50,6 +51,7 @@ void bind() {
     g_api.GetUniqueId = reinterpret_cast<decltype(g_api.GetUniqueId)>(dlsym(g_api.handle, "ncclGetUniqueId"));
     g_api.CommInitRank = reinterpret_cast<decltype(g_api.CommInitRank)>(dlsym(g_api.handle, "ncclCommInitRank"));
     g_api.CommDestroy = reinterpret_cast<decltype(g_api.CommDestroy)>(dlsym(g_api.handle, "ncclCommDestroy"));
+    g_api.CommCount = reinterpret_cast<decltype(g_api.CommCount)>(dlsym(g_api.handle, "ncclCommCount"));
     g_api.AllReduce = reinterpret_cast<decltype(g_api.AllReduce)>(dlsym(g_api.handle, "ncclAllReduce"));
     g_api.GetErrorString = reinterpret_cast<decltype(g_api.GetErrorString)>(dlsym(g_api.handle, "ncclGetErrorString"));
 }
@@ -93,6 +95,14 @@ extern "C" int mla_comm_destroy(void* comm) {
     if (!comm) return MLA_OK;
     if (int rc = api_ready()) return rc;
     if (int rc = g_api.CommDestroy(comm)) return nccl_fail("ncclCommDestroy", rc);
+    return MLA_OK;
+}
+
+extern "C" int mla_comm_count(void* comm, int* count) {
+    MLA_REQUIRE(comm && count, MLA_E_ARG, "bad comm_count arguments");
+    if (int rc = api_ready()) return rc;
+    MLA_REQUIRE(g_api.CommCount, MLA_E_LAUNCH, "the RCCL in the process lacks ncclCommCount");
+    if (int rc = g_api.CommCount(comm, count)) return nccl_fail("ncclCommCount", rc);
     return MLA_OK;
 }
 

@@ -252,10 +252,15 @@ class Dist:
     world == 1: every all-reduce is a no-op unless ``always`` (or MLA_DIST_ALWAYS=1) asks for the collectives anyway --
     a one-rank sum leaves the data unchanged, so the production branch can be exercised on a one-GPU box."""
 
-    def __init__(self, group=None, always=None):
+    def __init__(self, group=None, always=None, sync_bn=True):
+        """sync_bn: train-mode BatchNorm statistics are summed over the ranks (the step then equals the reference's single-process
+        step on the GLOBAL batch, train.py:119-142). False = per-shard statistics, the usual DistributedDataParallel semantics
+        (SURVEY.md section 8e allows either): no statistics all-reduce, the result equals the reference run per shard with
+        gradients averaged. trace: set to a list to record (tag, bytes, start event, end event) of every collective (bench.py)."""
         import os
         import torch.distributed as dist
         self.group, self.comm = group, None
+        self.sync_bn, self.trace = sync_bn, None
         inited = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if inited else 1
         self.rank = dist.get_rank(group) if inited else 0
@@ -315,9 +320,43 @@ class Dist:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
-    def all_reduce_sum(self, t):
+    def all_reduce_sum(self, t, tag="other"):
         """In-place sum over the group (see the class docstring for the transport)."""
-        return self._reduce(t) if self.active else t
+        if not self.active:
+            return t
+        if self.trace is None:
+            return self._reduce(t)
+        e0, e1 = _event(), _event()
+        e0.record()
+        self._reduce(t)
+        e1.record()
+        self.trace.append((tag, t.numel() * t.element_size(), e0, e1))
+        return t
+
+    @property
+    def bn_active(self):
+        return self.active and self.sync_bn
+
+    @property
+    def bn_world(self):
+        """Number of shards whose rows enter one BatchNorm statistic."""
+        return self.world if self.bn_active else 1
+
+    def ranks_reported(self):
+        """The rank count as the TRANSPORT reports it (ncclCommCount of this object's communicator, or the process group's size):
+        evidence that the collectives really span the ranks the launcher started."""
+        if self.comm is not None:
+            n = ctypes.c_int(-1)
+            _lib.check(_lib.lib().mla_comm_count(self.comm, ctypes.byref(n)))
+            return int(n.value)
+        import torch.distributed as dist
+        return dist.get_world_size(self.group) if self.active else 1
+
+    def describe(self):
+        origin = _lib.lib().mla_comm_library_origin().decode() if self.via == "abi" else None
+        return {"active": bool(self.active), "backend": self.backend, "transport": {"abi": "mla_allreduce_flat (C ABI -> ncclAllReduce)",
+                "torch": "torch.distributed.all_reduce", "host": "torch.distributed.all_reduce through host copies (gloo rehearsal)",
+                None: None}[self.via], "rccl_library_origin": origin, "ranks": self.ranks_reported(), "sync_bn": bool(self.sync_bn)}
 
 
 LOCAL = None          # set lazily (torch.distributed may not be initialised at import time)
@@ -328,6 +367,7 @@ def _local():
     if LOCAL is None:
         LOCAL = Dist.__new__(Dist)
         LOCAL.group, LOCAL.world, LOCAL.rank, LOCAL.active, LOCAL.comm, LOCAL.via = None, 1, 0, False, None, None
+        LOCAL.sync_bn, LOCAL.trace, LOCAL.backend = True, None, None
     return LOCAL
 
 
@@ -349,8 +389,9 @@ def bn_stats_sync(x, mode, period, dist, running_mean=None, running_var=None, mo
     sums = torch.empty(2 * ch, dtype=torch.float64, device=x.device)
     L = _lib.lib()
     _lib.check(L.mla_bn_stats_sums(_p(x), rows, cols, x.stride(0), mode, period, _p(_workspace(x.device)), _p(sums), _lib.stream_ptr()))
-    dist.all_reduce_sum(sums)
-    count = (rows // period * cols if mode == 0 else rows) * dist.world
+    if dist.bn_active:
+        dist.all_reduce_sum(sums, "syncbn_fwd")
+    count = (rows // period * cols if mode == 0 else rows) * dist.bn_world
     mean = torch.empty(ch, dtype=torch.float32, device=x.device)
     var = torch.empty(ch, dtype=torch.float32, device=x.device)
     _lib.check(L.mla_bn_stats_finish(_p(sums), ch, float(count), _p(mean), _p(var), _p(running_mean), _p(running_var),
@@ -374,9 +415,9 @@ def bn_backward(x, dy, yout, act, drop_scale, mode, period, mean, var, gamma, di
     _lib.check(L.mla_bn_bwd_sums(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(yout), ld_y, act, float(drop_scale), rows, cols, mode,
                                  period, _p(mean), _p(var), BN_EPS, _p(_workspace(x.device)), _p(local), _lib.stream_ptr()))
     glob = local
-    if dist.active:
-        glob = dist.all_reduce_sum(local.clone())
-    count = (rows // period * cols if mode == 0 else rows) * dist.world
+    if dist.bn_active:
+        glob = dist.all_reduce_sum(local.clone(), "syncbn_bwd")
+    count = (rows // period * cols if mode == 0 else rows) * dist.bn_world
     if want_dx and dx is None:
         dx = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
     _lib.check(L.mla_bn_bwd_apply(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(yout), ld_y, act, float(drop_scale), rows, cols, mode,

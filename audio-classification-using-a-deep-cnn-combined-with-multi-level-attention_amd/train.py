@@ -64,7 +64,7 @@ class TrainStep:
     (model.py:237-238); like torch's Adam (which skips ``grad is None``) they are left untouched.
     """
 
-    def __init__(self, clf, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, params=None):
+    def __init__(self, clf, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, params=None, sync_bn=True):
         """``params``: the parameters the caller's optimizer holds (``optimizer.param_groups[...]["params"]``); None =
         every parameter that requires grad. Exactly the tensors in ``params`` that require grad are updated, as
         ``optimizer.step()`` does in the reference (train.py:138; torch's Adam skips parameters whose ``.grad`` is None,
@@ -72,7 +72,10 @@ class TrainStep:
         never applies them (its ``__main__`` builds the Adam before ``set_requires_grad(clf, True)``, train.py:369-370 vs
         :96-97, so its "finetune" run only ever steps the MLA head) -- the updated model is the same."""
         self.clf, self.lr, self.betas, self.eps, self.t = clf, lr, betas, eps, 0
-        self.dist = ops.Dist(process_group)
+        # sync_bn=False: per-shard BatchNorm statistics under data parallelism (DistributedDataParallel semantics) instead of the
+        # global-batch statistics that reproduce the reference's single-process step; see ops.Dist
+        self.dist = ops.Dist(process_group, sync_bn=sync_bn)
+        self.exposed = None                                 # bench.py: list of (event, event) around the wait for the comm stream
         held = None if params is None else {id(p) for p in params}
         named = [(n, p) for n, p in clf.named_parameters()
                  if p.requires_grad and ".fcf." not in n and (held is None or id(p) in held)]
@@ -144,7 +147,7 @@ class TrainStep:
             self._comm_stream = torch.cuda.Stream(device=self.flat_g.device)
         self._comm_stream.wait_stream(cur)
         with torch.cuda.stream(self._comm_stream):
-            self.dist.all_reduce_sum(self.flat_g[a:b])
+            self.dist.all_reduce_sum(self.flat_g[a:b], "grad:" + name)
 
     def state_dict(self):
         """Optimizer state as plain tensors (Adam moments over the flat buffer + step count): what
@@ -196,14 +199,21 @@ class TrainStep:
                 cnn_train.backward(clf.cnn.cnn_model, cnn_tape, d_feats, self.grads, "cnn.cnn_model.", after_layer)
                 for b in pending:                          # buckets whose trigger layer lies below the lowest trained layer
                     self._reduce_bucket(b)
-                torch.cuda.current_stream().wait_stream(self._comm_stream)
+                if self.exposed is not None:               # how long the compute stream really waits for the exchange
+                    e0, e1 = ops._event(), ops._event()
+                    e0.record()
+                    torch.cuda.current_stream().wait_stream(self._comm_stream)
+                    e1.record()
+                    self.exposed.append((e0, e1))
+                else:
+                    torch.cuda.current_stream().wait_stream(self._comm_stream)
             elif self.finetune:
                 cnn_train.backward(clf.cnn.cnn_model, cnn_tape, d_feats, self.grads, "cnn.cnn_model.")
             if self.dist.active:
                 if not bucketed:
-                    self.dist.all_reduce_sum(self.flat_g)
-                self.dist.all_reduce_sum(loss)
-                self.dist.all_reduce_sum(hits)             # [running_corrects (train.py:142), #bad labels] over the global batch
+                    self.dist.all_reduce_sum(self.flat_g, "grad:flat")
+                self.dist.all_reduce_sum(loss, "loss")
+                self.dist.all_reduce_sum(hits, "hits")             # [running_corrects (train.py:142), #bad labels] over the global batch
             self.t += 1
             ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
             if self.finetune:                      # derived (repacked / bf16) weight copies are stale now

@@ -215,16 +215,21 @@ TRAIN_MFLOP_FWD = sum(CONV_MFLOP.values()) + sum(FC_MFLOP.values())       # per 
 TRAIN_MFLOP = {"frozen": TRAIN_MFLOP_FWD, "finetune": 3 * TRAIN_MFLOP_FWD - CONV_MFLOP["conv1"]}
 
 
-def make_train_step(bags, finetune, precision, rank, device):
+_TRAIN_SD = {}
+
+
+def make_train_step(bags, finetune, precision, rank, device, sync_bn=True):
     W = importlib.import_module(PKG + ".weights")
     M = importlib.import_module(PKG + ".model")
     TR = importlib.import_module(PKG + ".train")
     ens = M.Ensemble("repeat", CNN_CONF, [2, 1], device, precision=precision)
-    ens.load_state_dict({k: torch.as_tensor(v) for k, v in W.make_state_dict(7, W.ensemble_shapes((2, 1), False)).items()})
+    if not _TRAIN_SD:                                       # 73 M portable-seeded values: generated once per process
+        _TRAIN_SD.update(W.make_state_dict(7, W.ensemble_shapes((2, 1), False)))
+    ens.load_state_dict({k: torch.as_tensor(v) for k, v in _TRAIN_SD.items()})
     ens.to(device)
     if finetune:
         M.set_requires_grad(ens, True)
-    step = TR.TrainStep(ens, lr=1e-4 if finetune else 1e-3)
+    step = TR.TrainStep(ens, lr=1e-4 if finetune else 1e-3, sync_bn=sync_bn)
     x = torch.from_numpy(W.uniform(4000 + rank, 1, bags * T_BAG * 96 * 64, lo=-1.4, hi=4.6)).reshape(bags, T_BAG, 1, 96, 64).to(device)
     y = torch.from_numpy(W.bits24(4000 + rank, 2, bags) % 10).to(device)
     return step, x, y
@@ -260,6 +265,121 @@ def train_leg(device, bags=512, steps=5, warmup=2):
     return out
 
 
+def collective_summary(step, n_steps, world):
+    """What the data-parallel exchange of the timed steps looked like, from the events ops.Dist / TrainStep recorded on the
+    streams the collectives ran on (step.dist.trace, step.exposed): per step, averaged over the timed steps.
+    bus_GBps = 2 (N - 1) / N x bytes / time, the per-link figure ring all-reduces are judged by (xGMI: 7 links x ~153 GB/s per GPU).
+    overlap_hidden_frac = 1 - (time the compute stream waited for the communication stream) / (time of the gradient all-reduces)."""
+    per = {}
+    for tag, nbytes, e0, e1 in step.dist.trace:
+        d = per.setdefault(tag, [0, 0, 0.0])
+        d[0] += 1
+        d[1] += nbytes
+        d[2] += e0.elapsed_time(e1)
+    grad = {k: v for k, v in per.items() if k.startswith("grad:")}
+    bn = {k: v for k, v in per.items() if k.startswith("syncbn")}
+    g_bytes = sum(v[1] for v in grad.values()) / n_steps
+    g_ms = sum(v[2] for v in grad.values()) / n_steps
+    bn_ms = sum(v[2] for v in bn.values()) / n_steps
+    exposed_ms = sum(e0.elapsed_time(e1) for e0, e1 in (step.exposed or [])) / n_steps
+    bucketed = bool(step.exposed)
+    out = dict(step.dist.describe())
+    out.update({
+        "allreduce_bytes_per_step": g_bytes, "allreduce_ms": g_ms,
+        "bus_GBps": (2.0 * (world - 1) / world * g_bytes / (g_ms * 1e-3) / 1e9) if g_ms > 0 else None,
+        "gradient_messages_per_step": {k[5:]: {"bytes": v[1] // v[0], "ms": v[2] / v[0]} for k, v in grad.items()},
+        "syncbn_allreduces_per_step": sum(v[0] for v in bn.values()) / n_steps, "syncbn_allreduce_ms": bn_ms,
+        "syncbn_bytes_per_allreduce": (sum(v[1] for v in bn.values()) / max(sum(v[0] for v in bn.values()), 1)) if bn else None,
+        "other_allreduces_per_step": sum(v[0] for k, v in per.items() if k in ("loss", "hits", "other")) / n_steps,
+        "gradient_exchange": "buckets on a second HIP stream under the CNN backward" if bucketed else "one message on the compute stream",
+        "exposed_wait_ms": exposed_ms if bucketed else g_ms,
+        "overlap_hidden_frac": max(0.0, min(1.0, 1.0 - exposed_ms / g_ms)) if bucketed and g_ms > 0 else 0.0,
+    })
+    return out
+
+
+DP_VARIANTS = (("frozen_bf16", False, True), ("frozen_bf16_per_shard_bn", False, False), ("finetune_bf16", True, True))
+
+
+def dp_train_leg(world, rank, device, backend, bags=512, steps=5, warmup=2, variants=DP_VARIANTS):
+    """BASELINE config 5 inside the line the driver's scaling run produces (`python bench.py --gpus N`, N > 1): after the
+    inference headline EVERY rank runs the data-parallel train.py step (train.py:119-142: zero_grad -> forward -> CrossEntropyLoss
+    -> backward -> Adam) on its own `bags` bags of 96 x 64 log-mel -- global batch N x bags, 4096 at N = 8 -- with SyncBN sums and
+    the flat gradient buffer all-reduced over the group (RCCL through mla_allreduce_flat under backend nccl). Same barrier /
+    max-over-ranks timing as the headline. Returns (train_step, collective) sections; rank 0 prints them."""
+    import torch.distributed as dist
+    ops = importlib.import_module(PKG + ".ops")
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    out = {"bags_per_gpu": bags, "global_batch_bags": world * bags, "clips_per_step": world * bags * T_BAG, "n_gpus": world,
+           "steps": steps, "warmup": warmup}
+    coll = {}
+    for name, finetune, sync_bn in variants:
+        step, x, y = make_train_step(bags, finetune, "bf16", rank, device, sync_bn=sync_bn)
+        for _ in range(warmup):
+            loss, _ = step(x, y)
+        torch.cuda.synchronize()
+        step.dist.trace, step.exposed = [], []
+        loss, _ = step(x, y)                                   # one traced step to learn how many events a step needs
+        torch.cuda.synchronize()
+        per_step = 2 * len(step.dist.trace) + 2 * len(step.exposed)
+        step.dist.trace, step.exposed = [], []
+        ops.reserve_events(per_step * steps + 16)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, hits = step(x, y)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        kind = "finetune" if finetune else "frozen"
+        clips = world * bags * T_BAG
+        tf = clips * TRAIN_MFLOP[kind] * 1e6 * steps / elapsed / 1e12
+        assert bool(torch.isfinite(loss)), "non-finite loss in the data-parallel step"
+        out[name] = {"ms_per_step": elapsed / steps * 1e3, "clips_per_s": clips * steps / elapsed, "TFLOPs": tf,
+                     "peak": world * PEAK_TFLOPS["bf16"], "frac": tf / (world * PEAK_TFLOPS["bf16"]), "loss_last": float(loss),
+                     "hits_last_global": int(hits[0]), "trainable_floats": step.n_params, "sync_bn": sync_bn}
+        coll[name] = collective_summary(step, steps, world)
+        step.dist.trace = step.exposed = None
+        step.dist.close()
+        del step, x, y
+        torch.cuda.empty_cache()
+    return out, coll
+
+
+class Watchdog:
+    """Hard deadline for a leg that runs collectives nobody has executed on this machine before: if it has not finished after
+    `seconds`, `on_fire()` runs on a timer thread (rank 0 prints the line it has) and the process exits. A rank stuck in a
+    collective never returns to Python, so nothing softer works; every rank arms the same deadline, so all of them leave."""
+
+    def __init__(self, seconds, on_fire):
+        import threading
+        self.t = threading.Timer(seconds, self._fire)
+        self.t.daemon = True
+        self.on_fire = on_fire
+
+    def _fire(self):
+        try:
+            self.on_fire()
+        finally:
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
 def train_mode(args, world, rank, device):
     """BASELINE configs 4 / 5: one step = zero_grad -> forward -> CrossEntropyLoss -> backward -> Adam (train.py:124-138)
     on `bags` bags of 96 x 64 log-mel input per GPU (default 512; global batch = world x bags, 4096 at 8 GPUs), sharded by
@@ -269,7 +389,7 @@ def train_mode(args, world, rank, device):
     import torch.distributed as dist
     bags = args.bags if args.bags != 1024 else 512
     precision = args.precision
-    step, x, y = make_train_step(bags, args.finetune, precision, rank, device)
+    step, x, y = make_train_step(bags, args.finetune, precision, rank, device, sync_bn=not args.no_sync_bn)
 
     def barrier():
         if world > 1:
@@ -278,6 +398,15 @@ def train_mode(args, world, rank, device):
 
     for _ in range(args.warmup):
         loss, _ = step(x, y)
+    if world > 1:                                           # collective evidence: events on the streams the all-reduces run on
+        ops = importlib.import_module(PKG + ".ops")
+        torch.cuda.synchronize()
+        step.dist.trace, step.exposed = [], []
+        step(x, y)
+        torch.cuda.synchronize()
+        per_step = 2 * len(step.dist.trace) + 2 * len(step.exposed)
+        step.dist.trace, step.exposed = [], []
+        ops.reserve_events(per_step * args.steps + 16)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -305,6 +434,7 @@ def train_mode(args, world, rank, device):
             "roofline": {"bound": "mfma", "achieved": tf, "peak": world * PEAK_TFLOPS[precision], "unit": "TFLOP/s",
                          "frac": tf / (world * PEAK_TFLOPS[precision]), "traffic": None,
                          "flop_per_clip": TRAIN_MFLOP[kind] * 1e6, "what": "whole step, algorithmic conv + FC flops"},
+            "collective": collective_summary(step, args.steps, world) if world > 1 else None,
             "loss_last": float(loss)}), flush=True)
     if world > 1:
         dist.barrier()
@@ -377,7 +507,11 @@ def dry_run(args, world, rank):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": total, "mode": args.mode}), flush=True)
+        print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": total, "mode": args.mode,
+                          "legs": (["headline"] + ([] if args.no_train_leg else ["train_step", "collective"] if world > 1 else ["train_step"]))
+                                  if args.mode == "infer" else ["train"],
+                          "train_bags": args.train_bags, "train_steps": args.train_steps, "train_leg_timeout": args.train_leg_timeout,
+                          "dp_variants": [v[0] for v in DP_VARIANTS]}), flush=True)
 
 
 def main():
@@ -395,7 +529,11 @@ def main():
     ap.add_argument("--no-small-batch", action="store_true", help="skip the 1 020-clip eager / HIP-graph leg")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the bf16x3 (1e-4-parity arithmetic) leg")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg")
-    ap.add_argument("--no-train-leg", action="store_true", help="skip the config-4 training-step leg of the N = 1 line")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the training-step leg (config 4 at N = 1, the data-parallel config 5 step at N > 1)")
+    ap.add_argument("--train-bags", type=int, default=512, help="bags per GPU of the training-step leg (BASELINE configs 4 / 5: 512)")
+    ap.add_argument("--train-steps", type=int, default=5, help="timed steps per variant of the N > 1 training-step leg")
+    ap.add_argument("--train-leg-timeout", type=int, default=420, help="seconds the N > 1 training-step leg may take before rank 0 prints the line without it")
+    ap.add_argument("--no-sync-bn", action="store_true", help="--mode train: per-shard BatchNorm statistics (DDP semantics) instead of SyncBN")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse N>1 on one GPU)")
     ap.add_argument("--launch-timeout", type=int, default=1500, help="seconds the self-launched ranks may run")
     ap.add_argument("--prewarm-seconds", type=float, default=1.5,
@@ -556,9 +694,37 @@ def infer_mode(args, world, rank, device, ops):
         if world == 1 and not args.no_train_leg:
             del ens, pcm
             torch.cuda.empty_cache()
-            leg("train_step", lambda: train_leg(device))
-        print(json.dumps(result), flush=True)
+            leg("train_step", lambda: train_leg(device, bags=args.train_bags))
+        if world == 1 or args.no_train_leg:
+            print(json.dumps(result), flush=True)
     if world > 1:
+        if not args.no_train_leg:
+            # BASELINE config 5 in the line the driver's scaling run produces: every rank runs the data-parallel train step
+            state = {"printed": False}
+            ens = pcm = None
+            torch.cuda.empty_cache()
+
+            def give_up():
+                if rank == 0 and not state["printed"]:
+                    result["train_step"] = {"error": "the data-parallel train leg did not finish within %d s (rank 0 gave up waiting)" % args.train_leg_timeout}
+                    print(json.dumps(result), flush=True)
+                sys.stderr.write("bench.py: rank %d: data-parallel train leg timed out\n" % rank)
+
+            with Watchdog(args.train_leg_timeout, give_up):
+                try:
+                    ts, coll = dp_train_leg(world, rank, device, args.backend, bags=args.train_bags, steps=args.train_steps)
+                    if rank == 0:
+                        result["train_step"], result["collective"] = ts, coll
+                except Exception as e:                               # noqa: BLE001 -- reported in the line, not hidden
+                    if rank == 0:
+                        result["train_step"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    print("bench.py: rank %d: data-parallel train leg failed: %r" % (rank, e), file=sys.stderr, flush=True)
+                if rank == 0:
+                    print(json.dumps(result), flush=True)
+                    state["printed"] = True
+                dist.barrier()
+                dist.destroy_process_group()
+            return
         dist.barrier()
         dist.destroy_process_group()
 

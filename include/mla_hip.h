@@ -364,6 +364,7 @@ int mla_resample(const float* x, int64_t n_in, double sr_in, double sr_out, cons
 int         mla_comm_unique_id(void* id_host_128);
 int         mla_comm_init_rank(void** comm_out, int nranks, const void* id_host_128, int rank);
 int         mla_comm_destroy(void* comm);
+int         mla_comm_count(void* comm, int* count);   /* ncclCommCount: the number of ranks the communicator spans */
 const char* mla_comm_library_origin(void);   /* "already loaded by the host" | "loaded by libmla_hip" | "none" */
 
 /* In-place sum over the ranks of `comm` of a flat device buffer (ncclAllReduce, ncclSum), enqueued on `stream`:

@@ -45,8 +45,34 @@ def test_one_gpu_line_has_the_contract_fields_and_consistent_numbers():
     assert d["roofline_frontend"]["bound"] == "hbm" and 0 < d["roofline_frontend"]["frac"] < 1
 
 
-def test_two_self_launched_ranks_report_the_aggregate():
-    d = run_bench("--gpus", "2", "--backend", "gloo", "--bags", "32", "--steps", "2", "--warmup", "1", "--prewarm-seconds", "0.2")
+def test_two_self_launched_ranks_report_the_aggregate_and_the_data_parallel_train_step():
+    """`python bench.py --gpus 2` (the driver's scaling invocation; gloo here, two ranks sharing the test GPU): the inference
+    headline AND BASELINE config 5's data-parallel train step with the evidence of its collectives."""
+    d = run_bench("--gpus", "2", "--backend", "gloo", "--bags", "32", "--steps", "2", "--warmup", "1", "--prewarm-seconds", "0.2",
+                  "--train-bags", "32", "--train-steps", "2")
     assert d["n_gpus"] == 2 and d["config"]["clips_per_step_per_gpu"] == 320
     assert abs(d["value"] - 2 * 320 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]       # whole-job rate over max-over-ranks time
-    assert "cpu_baseline" not in d and "train_step" not in d                                  # N > 1: the headline line only
+    assert "cpu_baseline" not in d
+    ts, co = d["train_step"], d["collective"]
+    assert ts["bags_per_gpu"] == 32 and ts["global_batch_bags"] == 64 and ts["clips_per_step"] == 640 and ts["n_gpus"] == 2
+    for name in ("frozen_bf16", "frozen_bf16_per_shard_bn", "finetune_bf16"):
+        v, c = ts[name], co[name]
+        assert v["ms_per_step"] > 0 and abs(v["clips_per_s"] - 640 / (v["ms_per_step"] * 1e-3)) < 1e-6 * v["clips_per_s"]
+        assert 0 < v["frac"] < 1 and abs(v["loss_last"] - 2.3) < 0.3 and 0 <= v["hits_last_global"] <= 64
+        assert c["ranks"] == 2 and c["active"] and c["backend"] == "gloo" and "host copies" in c["transport"]
+        assert c["allreduce_bytes_per_step"] >= 4 * v["trainable_floats"] and c["allreduce_ms"] > 0 and c["bus_GBps"] > 0
+        assert c["other_allreduces_per_step"] == 2                                            # loss + hit counters
+        assert 0.0 <= c["overlap_hidden_frac"] <= 1.0
+    assert ts["frozen_bf16"]["trainable_floats"] == 823050 - 2 * 6010 and ts["finetune_bf16"]["trainable_floats"] == 72964234 - 2 * 6010
+    # SyncBN: 9 forward statistics (normv / normf share theirs) + 10 backward sums per step for MLA [2, 1]; none per shard
+    assert co["frozen_bf16"]["syncbn_allreduces_per_step"] == co["finetune_bf16"]["syncbn_allreduces_per_step"] > 10
+    assert co["frozen_bf16_per_shard_bn"]["syncbn_allreduces_per_step"] == 0 and not co["frozen_bf16_per_shard_bn"]["sync_bn"]
+    assert set(co["finetune_bf16"]["gradient_messages_per_step"]) == {"mla", "fc12", "fc0", "conv56", "conv14"}
+    assert set(co["frozen_bf16"]["gradient_messages_per_step"]) == {"flat"}
+    assert "second HIP stream" in co["finetune_bf16"]["gradient_exchange"]
+
+
+def test_train_mode_two_ranks_reports_the_collectives():
+    d = run_bench("--gpus", "2", "--backend", "gloo", "--mode", "train", "--bags", "16", "--steps", "2", "--warmup", "1")
+    assert d["n_gpus"] == 2 and d["config"]["global_batch_bags"] == 32 and d["collective"]["ranks"] == 2
+    assert d["collective"]["syncbn_allreduces_per_step"] > 10 and d["collective"]["allreduce_bytes_per_step"] >= 4 * 811030

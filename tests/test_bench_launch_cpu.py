@@ -31,6 +31,39 @@ def test_self_launch_two_ranks_prints_one_line():
     assert d["n_gpus"] == 2 and d["rank_sum"] == 1.0          # ranks 0 + 1 took part in the all-reduce
 
 
+def test_default_line_at_n_gt_1_carries_the_data_parallel_train_step():
+    """The driver's scaling run is `python bench.py --gpus N` with no mode flag: at N > 1 that line must hold the inference headline
+    AND the data-parallel train step (BASELINE config 5) with its collective section; flags reach the ranks."""
+    rc, lines, err = _run("--gpus", "2", "--dry-run", "--backend", "gloo")
+    assert rc == 0, err
+    d = json.loads(lines[0])
+    assert d["legs"] == ["headline", "train_step", "collective"] and d["train_bags"] == 512
+    assert d["dp_variants"] == ["frozen_bf16", "frozen_bf16_per_shard_bn", "finetune_bf16"]
+    rc, lines, err = _run("--gpus", "2", "--dry-run", "--backend", "gloo", "--train-bags", "32", "--train-steps", "3", "--train-leg-timeout", "99")
+    d = json.loads(lines[0])
+    assert (d["train_bags"], d["train_steps"], d["train_leg_timeout"]) == (32, 3, 99)
+    rc, lines, err = _run("--gpus", "2", "--dry-run", "--backend", "gloo", "--no-train-leg")
+    assert json.loads(lines[0])["legs"] == ["headline"]
+    rc, lines, err = _run("--dry-run")
+    assert json.loads(lines[0])["legs"] == ["headline", "train_step"]
+
+
+def test_watchdog_prints_what_it_has_and_leaves(tmp_path):
+    """bench.Watchdog: a leg stuck in a collective never returns to Python; the timer thread lets rank 0 print its line and exits 0."""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "with bench.Watchdog(0.5, lambda: print('{\"fired\": true}', flush=True)):\n"
+            "    time.sleep(30)\n"
+            "print('not reached')\n") % ROOT
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 0 and p.stdout.decode().strip() == '{"fired": true}'
+    code = ("import sys; sys.path.insert(0, %r); import bench\n"
+            "with bench.Watchdog(30, lambda: print('fired')):\n"
+            "    pass\n"
+            "print('done')\n") % ROOT
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 0 and p.stdout.decode().strip() == "done"
+
+
 def test_self_launch_train_mode_and_single():
     rc, lines, err = _run("--gpus", "2", "--dry-run", "--mode", "train")
     assert rc == 0 and json.loads(lines[0])["mode"] == "train", err
