@@ -134,7 +134,7 @@ def waveforms_to_examples(pcm, out_dtype=torch.float32, out=None):
     tab = device_tables(pcm.device)
     from . import ops
     _lib.check(ops._timed("logmel", _lib.lib().mla_logmel_examples,
-                          ctypes.c_void_p(pcm.data_ptr()), pcm_code, n_wave, n_samples, pcm.stride(0),
+                          ctypes.c_void_p(pcm.data_ptr()), pcm_code, n_wave, n_samples, pcm.stride(0) if n_wave > 1 else n_samples,   # (a size-1 dimension's stride is arbitrary)
                           ctypes.c_void_p(tab.data_ptr()), ctypes.c_void_p(out.data_ptr()), out_code, _lib.stream_ptr()))
     return out
 

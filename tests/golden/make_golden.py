@@ -248,6 +248,66 @@ def gen_ensemble(ref_model, vggish_input):
     return g
 
 
+def structured_waveforms():
+    """Two 10 s bags (160 000 samples each, float64) that are NOT noise -- closed-form tones and envelopes plus the portable RNG --
+    covering the regimes real recordings have and white noise does not: harmonic stacks under amplitude envelopes (strong spectral
+    peaks next to bands near the log offset), digital silence, a -60 dB passage, a chirp, decaying bursts, a low hum.
+    Regenerated identically by the tests (this function does not touch the reference)."""
+    sr, n = 16000, 160000
+    t = np.arange(n, dtype=np.float64) / sr
+    seg = lambda a, b: (t >= a) & (t < b)
+    # bag 0 "harmonic": 0-3 s a 220 Hz stack of 8 harmonics (1/k amplitudes) under a 2 Hz tremolo; 3-4.5 s digital silence;
+    # 4.5-7 s a 440 Hz stack of 5 harmonics fading out exponentially; 7-8.5 s a -60 dB passage (1 kHz tone + noise at 1e-3);
+    # 8.5-10 s two steady tones (1 kHz + 3.1 kHz) at full level
+    a = np.zeros(n)
+    s0 = seg(0.0, 3.0)
+    stack = sum(np.sin(2 * np.pi * 220.0 * k * t) / k for k in range(1, 9))
+    a[s0] = (0.25 * stack * (0.6 + 0.4 * np.sin(2 * np.pi * 2.0 * t)))[s0]
+    s2 = seg(4.5, 7.0)
+    stack2 = sum(np.sin(2 * np.pi * 440.0 * k * t + 0.3 * k) / k for k in range(1, 6))
+    a[s2] = (0.3 * stack2 * np.exp(-(t - 4.5) * 1.6))[s2]
+    s3 = seg(7.0, 8.5)
+    quiet = 1e-3 * (0.7 * np.sin(2 * np.pi * 1000.0 * t) + 0.3 * W.uniform(41, W.stream_id("structured/quiet"), n, dtype=np.float64))
+    a[s3] = quiet[s3]
+    s4 = seg(8.5, 10.0)
+    a[s4] = (0.4 * np.sin(2 * np.pi * 1000.0 * t) + 0.2 * np.sin(2 * np.pi * 3100.0 * t))[s4]
+    # bag 1 "chirp": 0-5 s a linear chirp 50 Hz -> 7 kHz; 5-6 s digital silence; 6-8.5 s five noise bursts with exponential decay
+    # (a transient every 0.5 s); 8.5-10 s a 60 Hz hum with its third harmonic, below the lowest mel band edge (125 Hz)
+    b = np.zeros(n)
+    c0 = seg(0.0, 5.0)
+    b[c0] = (0.7 * np.sin(2 * np.pi * (50.0 * t + 0.5 * (6950.0 / 5.0) * t ** 2)))[c0]
+    c2 = seg(6.0, 8.5)
+    noise = W.uniform(42, W.stream_id("structured/bursts"), n, dtype=np.float64)
+    b[c2] = (0.8 * noise * np.exp(-((t - 6.0) % 0.5) * 14.0))[c2]
+    c3 = seg(8.5, 10.0)
+    b[c3] = (0.5 * np.sin(2 * np.pi * 60.0 * t) + 0.1 * np.sin(2 * np.pi * 180.0 * t))[c3]
+    return {"harmonic": a, "chirp": b}
+
+
+def gen_structured(ref_model, vggish_mod, vggish_input):
+    """Wave -> log-mel examples -> embeddings -> class scores of the REFERENCE on the structured bags (both just_bottlenecks
+    settings), weights as in gen_ensemble."""
+    g = {}
+    waves = structured_waveforms()
+    names = sorted(waves)
+    exs = [vggish_input.waveform_to_examples(waves[k], 16000, return_tensor=False) for k in names]
+    for k, e in zip(names, exs):
+        assert e.shape == (10, 96, 64)
+        g["ex32/" + k] = e.astype(np.float32)
+        g["ex64_first/" + k] = e[:1]
+    x = torch.as_tensor(np.concatenate(exs)[:, None]).float()
+    dev = torch.device("cpu")
+    for jb in (False, True):
+        ens = ref_model.Ensemble("repeat", dict(CNN_CONF, just_bottlenecks=jb), [2, 1], dev)
+        load_ref_state(ens, W.make_state_dict(6, W.ensemble_shapes((2, 1), jb)))
+        ens.eval()
+        with torch.no_grad():
+            g["wave2logits/jb%d" % jb] = ens(x.reshape(2, 10, 1, 96, 64)).numpy()
+            if not jb:
+                g["embeddings"] = ens.cnn(x).numpy()           # (20, 128)
+    return g
+
+
 SUBSET_PARAMS = ("cnn.cnn_model.features.6.weight", "cnn.cnn_model.features.6.bias", "cnn.cnn_model.embeddings.2.weight",
                  "mla.embedded_mappings.1.fc.0.weight", "mla.fc.weight", "mla.fc.bias")
 
@@ -346,7 +406,7 @@ def save(name, g):
 def main():
     torch.set_num_threads(os.cpu_count() or 1)
     mel_features, vggish_input, vggish_mod, ref_model = import_reference()
-    which = set(sys.argv[1:]) or {"frontend", "vggish", "mla", "ensemble", "train", "dataset"}
+    which = set(sys.argv[1:]) or {"frontend", "vggish", "mla", "ensemble", "train", "dataset", "structured"}
     if "dataset" in which:
         save("dataset.npz", gen_dataset())
         which.discard("dataset")
@@ -362,6 +422,8 @@ def main():
         save("model_ensemble.npz", gen_ensemble(ref_model, vggish_input))
     if "train" in which:
         save("train.npz", gen_train(ref_model))
+    if "structured" in which:
+        save("structured.npz", gen_structured(ref_model, vggish_mod, vggish_input))
     assert not os.path.exists(os.path.join(REF, "__pycache__")), "bytecode leaked into the reference tree"
 
 

@@ -38,6 +38,11 @@ def test_waveform_to_examples_matches_reference_golden(vi, golden, mk):
         assert ok, (name, worst)
         if name.startswith(("noise", "stereo", "silence", "quiet")):
             assert np.abs(got - ref).max() <= 1e-4, (name, np.abs(got - ref).max())
+        else:
+            # tonal fixtures (sine, chirp): explicit LOG-domain bound too. The f32 FFT's floor (~6e-8 of the frame's strongest bin)
+            # sits under the reference's 0.01 log offset in bands the true spectrum leaves empty: d(log) = d(mel) / 0.01.
+            # tests/test_structured_gpu.py shows the scores stay within 1e-5 of the reference on such audio.
+            assert np.abs(got - ref).max() <= 2e-3, (name, np.abs(got - ref).max())
         arr = vi.waveform_to_examples(wav, 16000, return_tensor=False)
         assert isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.shape == ref.shape
         assert np.array_equal(arr.astype(np.float32), got)

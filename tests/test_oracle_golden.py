@@ -230,3 +230,30 @@ def test_resample_restatement_properties():
     for bad in ((np.zeros(2), 48000, 16000), (np.zeros(10), 0, 16000), (np.zeros(10), 16000, -1)):
         with pytest.raises(ValueError):
             ors.resample(*bad)
+
+
+def test_structured_audio_oracle_equals_reference(golden, mk, W):
+    """The oracle on audio that is NOT noise (harmonic stacks under envelopes, digital silence, a -60 dB passage, a chirp, decaying
+    bursts, a hum: make_golden.structured_waveforms) against what the reference produced: log-mel examples bit-equal after the
+    float32 cast, embeddings and class scores to float32 rounding."""
+    g = golden("structured")
+    waves = mk.structured_waveforms()
+    names = sorted(waves)
+    exs = []
+    for k in names:
+        e = ofe.waveform_to_examples(waves[k])
+        assert np.array_equal(e.astype(np.float32), g["ex32/" + k]), k
+        assert np.abs(e[:1] - g["ex64_first/" + k]).max() < 1e-12
+        exs.append(e)
+        lo = np.log(0.01)
+        # the fixture really covers the regimes it is there for: bands at the log offset next to loud ones
+        assert (e < lo + 1e-3).mean() > 0.05 and e.max() > 1.0, k
+    x = torch.as_tensor(np.concatenate(exs)).float()
+    for jb in (False, True):
+        sd = omodel.to_torch(W.make_state_dict(6, W.ensemble_shapes((2, 1), jb)))
+        with torch.no_grad():
+            out = omodel.ensemble_forward(sd, x.reshape(2, 10, 1, 96, 64), (2, 1), jb)
+            np.testing.assert_allclose(out.numpy(), g["wave2logits/jb%d" % jb], rtol=1e-4, atol=1e-6)
+            if not jb:
+                emb = omodel.vggish_forward(sd, x.reshape(20, 1, 96, 64), prefix="cnn.cnn_model.")
+                np.testing.assert_allclose(emb.numpy(), g["embeddings"], rtol=1e-4, atol=1e-4 * float(np.abs(g["embeddings"]).max()))
