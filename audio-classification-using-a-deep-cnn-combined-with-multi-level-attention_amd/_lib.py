@@ -112,6 +112,10 @@ def lib():
         L.mla_resample.argtypes = [vp, i64, cd, cd, vp, vp, ci, ci, vp, i64, vp]
         u64 = ctypes.c_uint64
         L.mla_dropout_mask.argtypes = [vp, i64, u64, u64, u64, cf, vp]
+        L.mla_dropout_mask_dev.argtypes = [vp, i64, u64, u64, vp, u64, cf, vp]
+        L.mla_adam_step_dev.argtypes = [vp, vp, vp, vp, i64, cf, cf, cf, vp, vp]
+        L.mla_adam_prepare.argtypes = [vp, cf, cf, cf, i64, vp]
+        L.mla_counter_add.argtypes = [vp, i64, vp]
         L.mla_comm_unique_id.argtypes = [vp]
         L.mla_comm_init_rank.argtypes = [ctypes.POINTER(vp), ci, vp, ci]
         L.mla_comm_destroy.argtypes = [vp]

@@ -105,17 +105,41 @@ __global__ void axpy_kernel(float a, const float* __restrict__ x, float* __restr
 
 // torch.optim.Adam single-tensor step (no weight decay, no amsgrad):
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// One update function for both kernel forms, with the fused multiply-adds written out and contraction off: left to the
+// compiler, `b1 * m + (1 - b1) * g` fuses around either product, and it chose differently in the two kernels (last-bit
+// differences between an eager step and its graph replay).
+__device__ __forceinline__ void adam_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                            float* __restrict__ v, int64_t i, float b1, float b2, float eps, float step_size,
+                                            float inv_sqrt_bc2) {
+#pragma clang fp contract(off)
+    const float gi = g[i];
+    const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+    const float vi = fmaf(b2, v[i], (1.f - b2) * (gi * gi));
+    m[i] = mi;
+    v[i] = vi;
+    const float den = fmaf(sqrtf(vi), inv_sqrt_bc2, eps);
+    p[i] = p[i] - step_size * mi / den;
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             int64_t n, float b1, float b2, float eps, float step_size, float inv_sqrt_bc2) {
-    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
-        const float gi = g[i];
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
-    }
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+        adam_update(p, g, m, v, i, b1, b2, eps, step_size, inv_sqrt_bc2);
 }
+
+// The same step with its two step-dependent scalars (lr / (1 - b1^t), 1 / sqrt(1 - b2^t)) read from device memory: a HIP graph
+// that holds this launch replays with the values of the moment, which mla_adam_prepare writes (computed on the host exactly as
+// mla_adam_step computes them, so both forms update the parameters bit for bit alike).
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                int64_t n, float b1, float b2, float eps, const float* __restrict__ scal) {
+    const float step_size = scal[0], inv_sqrt_bc2 = scal[1];
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+        adam_update(p, g, m, v, i, b1, b2, eps, step_size, inv_sqrt_bc2);
+}
+
+__global__ void set2_kernel(float* dst, float a, float b) { dst[0] = a; dst[1] = b; }
+
+__global__ void counter_add_kernel(int64_t* counter, int64_t delta) { *counter += delta; }
 
 // splitmix64 finaliser; the same three lines as weights.py _mix (uint64 wrap-around arithmetic only)
 __host__ __device__ inline uint64_t mix64(uint64_t z) {
@@ -128,6 +152,25 @@ __host__ __device__ inline uint64_t mix64(uint64_t z) {
 __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ mask, int64_t n, uint64_t key, uint64_t offset,
                                                            uint32_t thresh) {
     const uint64_t gold = 0x9E3779B97F4A7C15ull;
+    for (int64_t i0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) * 16; i0 < n; i0 += int64_t(gridDim.x) * blockDim.x * 16) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        _Pragma("unroll") for (int j = 0; j < 16; ++j) {
+            const uint64_t z = mix64((offset + uint64_t(i0 + j)) * gold + key);
+            w[j >> 2] |= uint32_t(uint32_t(z >> 40) >= thresh) << (8 * (j & 3));
+        }
+        if (i0 + 16 <= n && (reinterpret_cast<uintptr_t>(mask + i0) & 15) == 0) {
+            *reinterpret_cast<uint4*>(mask + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            for (int j = 0; j < 16 && i0 + j < n; ++j) mask[i0 + j] = uint8_t(w[j >> 2] >> (8 * (j & 3)));
+        }
+    }
+}
+
+// the same mask with stream_id = stream_base + *counter + 1 read on the device (graph replays draw a fresh mask per step)
+__global__ __launch_bounds__(256) void dropout_mask_dev_kernel(uint8_t* __restrict__ mask, int64_t n, uint64_t seed, uint64_t stream_base,
+                                                               const int64_t* __restrict__ counter, uint64_t offset, uint32_t thresh) {
+    const uint64_t gold = 0x9E3779B97F4A7C15ull;
+    const uint64_t key = mix64(seed * gold + stream_base + uint64_t(*counter) + 1ull);
     for (int64_t i0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) * 16; i0 < n; i0 += int64_t(gridDim.x) * blockDim.x * 16) {
         uint32_t w[4] = {0, 0, 0, 0};
         _Pragma("unroll") for (int j = 0; j < 16; ++j) {
@@ -195,6 +238,43 @@ extern "C" int mla_adam_step(float* p, const float* g, float* m, float* v, int64
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n, beta1, beta2,
                        eps, float(double(lr) / bc1), float(1.0 / sqrt(bc2)));
     MLA_LAUNCH_OK("adam");
+    return MLA_OK;
+}
+
+extern "C" int mla_adam_prepare(float* scal2_dev, float lr, float beta1, float beta2, int64_t step, mla_stream_t stream) {
+    MLA_REQUIRE(scal2_dev && step >= 1, MLA_E_ARG, "bad adam_prepare arguments");
+    const double bc1 = 1.0 - pow(double(beta1), double(step)), bc2 = 1.0 - pow(double(beta2), double(step));
+    hipLaunchKernelGGL(set2_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), scal2_dev, float(double(lr) / bc1),
+                       float(1.0 / sqrt(bc2)));
+    MLA_LAUNCH_OK("adam_prepare");
+    return MLA_OK;
+}
+
+extern "C" int mla_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
+                                 const float* scal2_dev, mla_stream_t stream) {
+    MLA_REQUIRE(p && g && m && v && scal2_dev && n >= 0, MLA_E_ARG, "bad adam arguments");
+    if (n == 0) return MLA_OK;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n, beta1, beta2,
+                       eps, scal2_dev);
+    MLA_LAUNCH_OK("adam (scalars on the device)");
+    return MLA_OK;
+}
+
+extern "C" int mla_counter_add(int64_t* counter_dev, int64_t delta, mla_stream_t stream) {
+    MLA_REQUIRE(counter_dev, MLA_E_ARG, "null counter");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), counter_dev, delta);
+    MLA_LAUNCH_OK("counter_add");
+    return MLA_OK;
+}
+
+extern "C" int mla_dropout_mask_dev(uint8_t* mask, int64_t n, uint64_t seed, uint64_t stream_base, const int64_t* counter_dev,
+                                    uint64_t offset, float p_drop, mla_stream_t stream) {
+    MLA_REQUIRE(mask && counter_dev && n >= 0 && p_drop >= 0.f && p_drop <= 1.f, MLA_E_ARG, "bad dropout_mask arguments");
+    if (n == 0) return MLA_OK;
+    const uint32_t thresh = uint32_t(llround(double(p_drop) * double(1 << 24)));
+    hipLaunchKernelGGL(dropout_mask_dev_kernel, dim3(grid_for((n + 15) / 16)), dim3(256), 0, static_cast<hipStream_t>(stream), mask, n, seed,
+                       stream_base, counter_dev, offset, thresh);
+    MLA_LAUNCH_OK("dropout_mask (device stream count)");
     return MLA_OK;
 }
 

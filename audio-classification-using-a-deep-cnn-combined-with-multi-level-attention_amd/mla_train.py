@@ -11,9 +11,12 @@ from .params import DR, H, K, T
 class Ctx:
     """Per-step context: the tape of saved activations and the data-parallel group (SyncBN)."""
 
-    def __init__(self, tape=False, dist=None):
+    def __init__(self, tape=False, dist=None, counter=None, bases=None):
+        """counter / bases: set while the training step is being captured into a HIP graph -- a device int64 holding the number of
+        completed steps and {id(Dropout module): its call count minus that number}; masks are then drawn by call number on the device."""
         self.tape = [] if tape else None
         self.dist = dist or ops._local()
+        self.counter, self.bases = counter, bases
 
 
 def _bn_stats(bn, z, mode, period, train, ctx):
@@ -39,7 +42,11 @@ def embedded_mapping_forward(em, x, ctx=None):
     for j in range(em.n_fc):
         z = ops.linear(h, em.fc[j].weight.detach(), em.fc[j].bias.detach())
         mean, var = _bn_stats(em.norms[j], z, 0, T, train, ctx)
-        keep = em.dropouts[j].keep_mask(z.numel(), z.device, offset=ctx.dist.rank * z.numel()) if train else None
+        if train and ctx.counter is not None:
+            d = em.dropouts[j]
+            keep = d.keep_mask_dev(z.numel(), z.device, ctx.dist.rank * z.numel(), ctx.counter, ctx.bases[id(d)])
+        else:
+            keep = em.dropouts[j].keep_mask(z.numel(), z.device, offset=ctx.dist.rank * z.numel()) if train else None
         h_in = h
         h = ops.bn_apply(z, 0, T, mean, var, em.norms[j].weight.detach(), em.norms[j].bias.detach(), act=1,
                          keep_mask=keep, drop_scale=1.0 / (1.0 - DR))

@@ -61,6 +61,11 @@ class Dropout(nn.Module):
         self.calls += 1
         return ops.dropout_mask(numel, self.seed, (self.ordinal << 32) + self.calls, offset, self.p, device)
 
+    def keep_mask_dev(self, numel, device, offset, counter, base):
+        """The mask of call number base + counter[0] + 1 of this module, the call number read ON THE DEVICE: what a HIP graph of
+        the training step records, so that every replay draws the next mask of the sequence keep_mask() would have drawn."""
+        return ops.dropout_mask_dev(numel, self.seed, (self.ordinal << 32) + base, counter, offset, self.p, device)
+
     def forward(self, x):
         raise RuntimeError("Dropout is fused into the HIP BatchNorm/ReLU kernel of its parent module")
 

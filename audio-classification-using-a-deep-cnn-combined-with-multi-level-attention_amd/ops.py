@@ -510,6 +510,30 @@ def cross_entropy(scores, labels, inv_total, want_grad=True):
     return loss, d, hits
 
 
+def dropout_mask_dev(n, seed, stream_base, counter, offset, p_drop, device, out=None):
+    """dropout_mask with stream_id = stream_base + counter[0] + 1 read on the device (graph-captured training step)."""
+    assert counter.dtype == torch.int64 and counter.is_cuda
+    if out is None:
+        out = torch.empty(n, dtype=torch.uint8, device=device)
+    _lib.check(_lib.lib().mla_dropout_mask_dev(_p(out), n, int(seed) & (2 ** 64 - 1), int(stream_base) & (2 ** 64 - 1), _p(counter), int(offset),
+                                               float(p_drop), _lib.stream_ptr()))
+    return out
+
+
+def adam_prepare(scal, lr, beta1, beta2, step):
+    """Write Adam's step-dependent scalars for step `step` into the device pair adam_step_dev reads (an ordinary launch, enqueued in
+    front of a graph replay)."""
+    assert scal.dtype == torch.float32 and scal.is_cuda and scal.numel() == 2
+    _lib.check(_lib.lib().mla_adam_prepare(_p(scal), float(lr), float(beta1), float(beta2), int(step), _lib.stream_ptr()))
+
+
+def adam_step_dev(p, g, m, v, beta1, beta2, eps, scal, counter):
+    """adam_step with its step-dependent scalars read from `scal` (adam_prepare), then counter += 1 (both graph-capturable)."""
+    L = _lib.lib()
+    _lib.check(L.mla_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), float(beta1), float(beta2), float(eps), _p(scal), _lib.stream_ptr()))
+    _lib.check(L.mla_counter_add(_p(counter), 1, _lib.stream_ptr()))
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
     _lib.check(_lib.lib().mla_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
                                         int(step), _lib.stream_ptr()))

@@ -64,7 +64,7 @@ class TrainStep:
     (model.py:237-238); like torch's Adam (which skips ``grad is None``) they are left untouched.
     """
 
-    def __init__(self, clf, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, params=None, sync_bn=True):
+    def __init__(self, clf, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, params=None, sync_bn=True, graph=None):
         """``params``: the parameters the caller's optimizer holds (``optimizer.param_groups[...]["params"]``); None =
         every parameter that requires grad. Exactly the tensors in ``params`` that require grad are updated, as
         ``optimizer.step()`` does in the reference (train.py:138; torch's Adam skips parameters whose ``.grad`` is None,
@@ -76,6 +76,10 @@ class TrainStep:
         # global-batch statistics that reproduce the reference's single-process step; see ops.Dist
         self.dist = ops.Dist(process_group, sync_bn=sync_bn)
         self.exposed = None                                 # bench.py: list of (event, event) around the wait for the comm stream
+        # use_graph: replay the whole step as one HIP graph from the second step of a batch shape on (single process only; env
+        # MLA_TRAIN_GRAPH=0 or graph=False keeps every step eager)
+        self.use_graph = (os.environ.get("MLA_TRAIN_GRAPH", "1") == "1") if graph is None else bool(graph)
+        self._graph, self._eager_shape, self._dev_t = None, None, -1
         held = None if params is None else {id(p) for p in params}
         named = [(n, p) for n, p in clf.named_parameters()
                  if p.requires_grad and ".fcf." not in n and (held is None or id(p) in held)]
@@ -96,6 +100,8 @@ class TrainStep:
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)       # completed steps: the dropout call counter of the graph-captured step
+        self.adam_scal = torch.zeros(2, dtype=torch.float32, device=dev)    # Adam's step-dependent scalars, written in front of each replay
         self.grads, self._seated, off = {}, [], 0
         spans = {}                                        # bucket id -> [first float, one past the last] of the flat buffers
         for n, p in named:
@@ -164,64 +170,126 @@ class TrainStep:
     def __call__(self, inputs, labels):
         """inputs (B, T, 1, 96, 64) (or whatever ``clf.input`` reshapes), labels (B,) int64.
         Returns (loss, hits) as device tensors (no host sync; train.py:141-142 syncs via .item()): hits = int32
-        [n_correct, n_labels_out_of_range] over the global batch (``ops.raise_on_bad_labels(hits)`` -> n_correct or IndexError)."""
+        [n_correct, n_labels_out_of_range] over the global batch (``ops.raise_on_bad_labels(hits)`` -> n_correct or IndexError).
+        With the HIP graph in use the two tensors (and ``last_out``) are the graph's own buffers: valid until the next step."""
         clf = self.clf
         for n, p, ptr in self._seated:
             if p.data_ptr() != ptr:
                 raise RuntimeError("parameter %s no longer lives in the flat buffer of this TrainStep (the model was moved or "
                                    "cast after the step was built): build a new TrainStep" % n)
         clf.train()
-        B_global = inputs.shape[0] * self.dist.world
+        ops.check_labels(labels, clf.num_classes)
+        if self._graph_usable(inputs):
+            return self._graphed(inputs, labels)
         with torch.no_grad():
-            x = clf.input(inputs)
-            if self.finetune:
-                feats, cnn_tape = cnn_train.forward(clf.cnn.cnn_model, x, clf.cnn.precision)
-            else:
-                feats = clf.cnn(x)
-            ctx = mla_train.Ctx(tape=True, dist=self.dist)
-            out = mla_train.mla_forward(clf.mla, feats.reshape(-1, T, clf.emb_input_size), ctx)
-            ops.check_labels(labels, out.shape[1])
-            loss, dout, hits = ops.cross_entropy(out, labels.to(out.device).long().contiguous(), 1.0 / B_global)
-            d_feats = mla_train.mla_backward(clf.mla, ctx, dout, self.mla_grads, need_input_grad=self.finetune)
-            bucketed = self.dist.active and self.finetune and self.overlap
-            if bucketed:
-                # the head's gradients are final: reduce them while the CNN backward runs; each CNN bucket follows as soon as
-                # the lowest layer it holds is done. No other collective is issued until the compute stream has waited for
-                # the communication stream below, so the two streams never use the communicator at the same time.
-                pending = [b for b in ("mla", "fc12", "fc0", "conv56", "conv14") if b in self.buckets]
-                if "mla" in pending:
-                    self._reduce_bucket("mla"); pending.remove("mla")
+            loss, hits, out = self._body(inputs, labels.to(inputs.device).long().contiguous(), captured=False)
+        self._eager_shape = tuple(inputs.shape)
+        self.last_out = out
+        return loss, hits
 
-                def after_layer(pos):
-                    for b in list(pending):
-                        if self.BUCKET_TRIGGER[b] == pos:
-                            self._reduce_bucket(b); pending.remove(b)
-                cnn_train.backward(clf.cnn.cnn_model, cnn_tape, d_feats, self.grads, "cnn.cnn_model.", after_layer)
-                for b in pending:                          # buckets whose trigger layer lies below the lowest trained layer
-                    self._reduce_bucket(b)
-                if self.exposed is not None:               # how long the compute stream really waits for the exchange
-                    e0, e1 = ops._event(), ops._event()
-                    e0.record()
-                    torch.cuda.current_stream().wait_stream(self._comm_stream)
-                    e1.record()
-                    self.exposed.append((e0, e1))
-                else:
-                    torch.cuda.current_stream().wait_stream(self._comm_stream)
-            elif self.finetune:
-                cnn_train.backward(clf.cnn.cnn_model, cnn_tape, d_feats, self.grads, "cnn.cnn_model.")
-            if self.dist.active:
-                if not bucketed:
-                    self.dist.all_reduce_sum(self.flat_g, "grad:flat")
-                self.dist.all_reduce_sum(loss, "loss")
-                self.dist.all_reduce_sum(hits, "hits")             # [running_corrects (train.py:142), #bad labels] over the global batch
+    # ---- the step as ONE HIP graph (no data-parallel group): ~130 small launches of the head's forward / backward / Adam and the
+    # CNN's kernels become one graph launch; what the host used to pass per step -- Adam's step count, the dropout call number --
+    # is read from device memory instead (mla_adam_prepare + mla_adam_step_dev, mla_dropout_mask_dev), so a replay is a real next step.
+
+    def _dropouts(self):
+        return [m for m in self.clf.mla.modules() if type(m).__name__ == "Dropout"]
+
+    def _graph_usable(self, inputs):
+        if not self.use_graph or self.dist.active or ops.profile is not None or not inputs.is_cuda or inputs.dtype != torch.float32:
+            return False
+        if not inputs.is_contiguous() or any(d.mask is not None for d in self._dropouts()):
+            return False                      # injected masks change per step on the host: the eager path
+        # first step of a shape runs eagerly: it sizes the library's workspaces and warms the weight caches outside any capture
+        return self._eager_shape == tuple(inputs.shape)
+
+    def _graphed(self, inputs, labels):
+        dev = inputs.device
+        drops = self._dropouts()
+        g = self._graph
+        if g is not None and (g["shape"] != tuple(inputs.shape) or any(d.calls - self.t != g["bases"][id(d)] for d in drops)):
+            g = self._graph = None                                 # another batch size, or somebody else drew masks in between
+        if self._dev_t != self.t:
+            self.step_dev.fill_(self.t)
+            self._dev_t = self.t
+        if g is None:
+            g = {"shape": tuple(inputs.shape), "x": inputs, "y": labels.to(dev).long().contiguous().clone(),
+                 "bases": {id(d): d.calls - self.t for d in drops}}
+            torch.cuda.synchronize()
+            g["graph"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g["graph"], capture_error_mode="relaxed"), torch.no_grad():
+                g["loss"], g["hits"], g["out"] = self._body(g["x"], g["y"], captured=True, bases=g["bases"])
+            self._graph = g
+        else:
+            if inputs.data_ptr() != g["x"].data_ptr():
+                g["x"].copy_(inputs, non_blocking=True)
+            g["y"].copy_(labels.to(dev, non_blocking=True).long(), non_blocking=True)
+        ops.adam_prepare(self.adam_scal, self.lr, self.betas[0], self.betas[1], self.t + 1)
+        g["graph"].replay()
+        self.t += 1
+        self._dev_t = self.t
+        for d in drops:
+            d.calls += 1
+        if self.finetune:                          # the graph re-derives its own weight copies; anything cached outside it is stale
+            for m in self.clf.cnn.modules():
+                if hasattr(m, "_cache"):
+                    m._cache.key = None
+        self.last_out = g["out"]
+        return g["loss"], g["hits"]
+
+    def _body(self, inputs, labels, captured, bases=None):
+        """The kernel sequence of one step (train.py:124-138). captured: being recorded into the HIP graph."""
+        clf = self.clf
+        B_global = inputs.shape[0] * self.dist.world
+        x = clf.input(inputs)
+        if self.finetune:
+            feats, cnn_tape = cnn_train.forward(clf.cnn.cnn_model, x, clf.cnn.precision)
+        else:
+            feats = clf.cnn(x)
+        ctx = mla_train.Ctx(tape=True, dist=self.dist, counter=self.step_dev if captured else None, bases=bases)
+        out = mla_train.mla_forward(clf.mla, feats.reshape(-1, T, clf.emb_input_size), ctx)
+        loss, dout, hits = ops.cross_entropy(out, labels, 1.0 / B_global)
+        d_feats = mla_train.mla_backward(clf.mla, ctx, dout, self.mla_grads, need_input_grad=self.finetune)
+        bucketed = self.dist.active and self.finetune and self.overlap
+        if bucketed:
+            # the head's gradients are final: reduce them while the CNN backward runs; each CNN bucket follows as soon as
+            # the lowest layer it holds is done. No other collective is issued until the compute stream has waited for
+            # the communication stream below, so the two streams never use the communicator at the same time.
+            pending = [b for b in ("mla", "fc12", "fc0", "conv56", "conv14") if b in self.buckets]
+            if "mla" in pending:
+                self._reduce_bucket("mla"); pending.remove("mla")
+
+            def after_layer(pos):
+                for b in list(pending):
+                    if self.BUCKET_TRIGGER[b] == pos:
+                        self._reduce_bucket(b); pending.remove(b)
+            cnn_train.backward(clf.cnn.cnn_model, cnn_tape, d_feats, self.grads, "cnn.cnn_model.", after_layer)
+            for b in pending:                          # buckets whose trigger layer lies below the lowest trained layer
+                self._reduce_bucket(b)
+            if self.exposed is not None:               # how long the compute stream really waits for the exchange
+                e0, e1 = ops._event(), ops._event()
+                e0.record()
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
+                e1.record()
+                self.exposed.append((e0, e1))
+            else:
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
+        elif self.finetune:
+            cnn_train.backward(clf.cnn.cnn_model, cnn_tape, d_feats, self.grads, "cnn.cnn_model.")
+        if self.dist.active:
+            if not bucketed:
+                self.dist.all_reduce_sum(self.flat_g, "grad:flat")
+            self.dist.all_reduce_sum(loss, "loss")
+            self.dist.all_reduce_sum(hits, "hits")             # [running_corrects (train.py:142), #bad labels] over the global batch
+        if captured:
+            ops.adam_step_dev(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.betas[0], self.betas[1], self.eps, self.adam_scal, self.step_dev)
+        else:
             self.t += 1
             ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
             if self.finetune:                      # derived (repacked / bf16) weight copies are stale now
                 for m in clf.cnn.modules():
                     if hasattr(m, "_cache"):
                         m._cache.key = None
-        self.last_out = out
-        return loss, hits
+        return loss, hits, out
 
 
 def _evaluate(clf, loader, device, collect=False):

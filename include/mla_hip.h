@@ -340,6 +340,15 @@ int mla_col_sum_bf16(const void* x, int64_t ldx, int64_t rows, int64_t cols, voi
 /* torch.optim.Adam step t (train.py:369; no weight decay, no amsgrad) over one flat buffer. */
 int mla_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, int64_t step, mla_stream_t stream);
+/* The same step with its two step-dependent scalars read from device memory (scal2_dev[0] = lr / (1 - beta1^t), [1] = 1 / sqrt(1 -
+ * beta2^t)), so that a HIP graph holding the launch replays train.py:138 with the step count of the moment (the host form bakes
+ * them into the launch). mla_adam_prepare writes them for step t, computed on the host exactly as mla_adam_step does: enqueue it
+ * in front of every replay. */
+int mla_adam_prepare(float* scal2_dev, float lr, float beta1, float beta2, int64_t step, mla_stream_t stream);
+int mla_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
+                      const float* scal2_dev, mla_stream_t stream);
+/* *counter_dev += delta: the call counter mla_dropout_mask_dev reads, advanced once per step from inside the graph */
+int mla_counter_add(int64_t* counter_dev, int64_t delta, mla_stream_t stream);
 
 /* vggish_input.py:52-53 `resampy.resample(data, sample_rate, 16000)`: band-limited sinc interpolation (resampy/interpn.py)
  * of a mono float32 waveform. win / delta: DEVICE tables of the interpolation filter in double precision (right half of the
@@ -380,6 +389,10 @@ int mla_allreduce_flat(void* buf, int64_t count, int dtype, void* comm, mla_stre
  * single-process run. Consumed by mla_bn_apply (keep_mask argument). */
 int mla_dropout_mask(uint8_t* mask, int64_t n, uint64_t seed, uint64_t stream_id, uint64_t offset, float p_drop,
                      mla_stream_t stream);
+/* The same mask with stream_id = stream_base + *counter_dev + 1 read on the device: inside a HIP graph of the training step
+ * every replay draws the next mask of the module's sequence (model.py:213 draws a fresh one per forward). */
+int mla_dropout_mask_dev(uint8_t* mask, int64_t n, uint64_t seed, uint64_t stream_base, const int64_t* counter_dev,
+                         uint64_t offset, float p_drop, mla_stream_t stream);
 
 #ifdef __cplusplus
 }
