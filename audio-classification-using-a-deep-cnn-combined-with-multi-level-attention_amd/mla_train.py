@@ -23,9 +23,7 @@ def _bn_stats(bn, z, mode, period, train, ctx):
     """(mean, var) to normalise with: batch statistics in train mode (running buffers updated in
     place, torch semantics; sums all-reduced over the data-parallel group), else running ones."""
     if train:
-        mean, var = ops.bn_stats_sync(z, mode, period, ctx.dist, bn.running_mean, bn.running_var, bn.momentum)
-        bn.num_batches_tracked += 1
-        return mean, var
+        return ops.bn_stats_sync(z, mode, period, ctx.dist, bn.running_mean, bn.running_var, bn.momentum, tracked=bn.num_batches_tracked)
     return bn.running_mean, bn.running_var
 
 
@@ -64,9 +62,8 @@ def attention_forward(am, h, y, ctx=None, level=0):
     if am.training:
         # both norms see the same z, hence the same batch statistics; each keeps its own buffers
         mean, var = ops.bn_stats_sync(z, 0, T, ctx.dist, am.normv.running_mean, am.normv.running_var, am.normv.momentum,
-                                      also=((am.normf.running_mean, am.normf.running_var, am.normf.momentum),))
-        am.normv.num_batches_tracked += 1
-        am.normf.num_batches_tracked += 1
+                                      also=((am.normf.running_mean, am.normf.running_var, am.normf.momentum, am.normf.num_batches_tracked),),
+                                      tracked=am.normv.num_batches_tracked)
         nv = (mean, var, am.normv.weight.detach(), am.normv.bias.detach())
         nf = (mean, var, am.normf.weight.detach(), am.normf.bias.detach())
     else:

@@ -379,10 +379,11 @@ def dropout_mask(n, seed, stream_id, offset, p_drop, device):
     return out
 
 
-def bn_stats_sync(x, mode, period, dist, running_mean=None, running_var=None, momentum=-1.0, also=()):
+def bn_stats_sync(x, mode, period, dist, running_mean=None, running_var=None, momentum=-1.0, also=(), tracked=None):
     """bn_stats with the (sum, sum of squares) all-reduced over the data-parallel group. `also`: further (running_mean,
     running_var, momentum) triples to update from the SAME statistics (two BatchNorms fed by one tensor, model.py:239-240:
-    one pass over x and one all-reduce instead of two)."""
+    one pass over x and one all-reduce instead of two). tracked: the BatchNorm's num_batches_tracked (int64 device scalar), advanced
+    by the finishing kernel; `also` entries are (running_mean, running_var, momentum, tracked)."""
     _chk(x, torch.float32)
     rows, cols = x.shape
     ch = period if mode == 0 else cols
@@ -395,10 +396,11 @@ def bn_stats_sync(x, mode, period, dist, running_mean=None, running_var=None, mo
     mean = torch.empty(ch, dtype=torch.float32, device=x.device)
     var = torch.empty(ch, dtype=torch.float32, device=x.device)
     _lib.check(L.mla_bn_stats_finish(_p(sums), ch, float(count), _p(mean), _p(var), _p(running_mean), _p(running_var),
-                                     float(momentum), _lib.stream_ptr()))
-    for rm, rv, mom in also:
+                                     float(momentum), _p(tracked), _lib.stream_ptr()))
+    for rm, rv, mom, trk in also:
         scratch_m, scratch_v = torch.empty_like(mean), torch.empty_like(var)
-        _lib.check(L.mla_bn_stats_finish(_p(sums), ch, float(count), _p(scratch_m), _p(scratch_v), _p(rm), _p(rv), float(mom), _lib.stream_ptr()))
+        _lib.check(L.mla_bn_stats_finish(_p(sums), ch, float(count), _p(scratch_m), _p(scratch_v), _p(rm), _p(rv), float(mom), _p(trk),
+                                         _lib.stream_ptr()))
     return mean, var
 
 

@@ -219,7 +219,8 @@ int mla_attention_pool(const float* z, int64_t bags, int T, int K, const float* 
 int mla_bn_stats_sums(const float* x, int64_t rows, int64_t cols, int64_t ldx, int mode, int period,
                       void* workspace, double* sums, mla_stream_t stream);
 int mla_bn_stats_finish(const double* sums, int channels, double count, float* mean, float* var_biased,
-                        float* running_mean, float* running_var, float momentum, mla_stream_t stream);
+                        float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked /* += 1, or NULL */,
+                        mla_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Training step: train.py:124-138 (zero_grad, forward, CrossEntropyLoss, backward, Adam)

@@ -14,6 +14,14 @@ from oracle import model as omodel
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _inference_only():
+    """These are forward-parity tests (the goldens were produced under torch.no_grad()): without it a module whose parameters
+    require grad records its HIP stages for autograd, as a torch module would (tests/test_autograd_gpu.py covers that path)."""
+    with torch.no_grad():
+        yield
+
 CNN_CONF = dict(cnn_type="vggish", num_classes=10, use_pretrained=False, just_bottlenecks=False,
                 cnn_trainable=False, first_cnn_layer_trainable=False, in_channels=1)
 
