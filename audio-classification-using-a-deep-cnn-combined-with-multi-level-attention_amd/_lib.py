@@ -68,6 +68,7 @@ def lib():
         L.mla_linear_small.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, vp]
         L.mla_linear_narrow.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, vp]
         L.mla_linear_splitk.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, ci, ci, vp, i64, vp]
+        L.mla_linear_ksplit.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, ci, ci, ci, ci, vp, i64, vp]
         L.mla_bn_stats_workspace_bytes.restype = i64
         L.mla_bn_stats.argtypes = [vp, i64, i64, i64, ci, ci, vp, vp, vp, vp, vp, cf, vp]
         L.mla_bn_apply.argtypes = [vp, i64, vp, i64, i64, i64, ci, ci, vp, vp, vp, vp, cf, ci, vp, cf, vp]

@@ -43,6 +43,9 @@ __device__ unsigned long long g_gemm_stamps[8][2][8];
 #ifndef MLA_GEMM_TILE320
 #define MLA_GEMM_TILE320 1
 #endif
+#ifndef MLA_GEMM_RING
+#define MLA_GEMM_RING 1             // 0: A/B builds without the four-stage ring form of the small-batch 128 x 128 tiles
+#endif
 // timing experiment only (wrong results): -DMLA_GEMM_KWRAP=8 keeps every tile's operands inside 8 K stages, i.e. L2-resident
 #ifdef MLA_GEMM_KWRAP
 #define MLA_GEMM_KW(s) ((s) & (MLA_GEMM_KWRAP - 1))
@@ -280,6 +283,137 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const T* __restrict__
     }
 }
 
+// ---- small-batch form: 128 x 128 tiles behind a FOUR-stage LDS ring --------------------------------------------------------
+// At ~1 000 rows (BASELINE config 3 read literally: 1 020 clips per step) the FC layers have only enough 128 x 128 tiles to
+// give every CU one, each tile streams its whole K range (32 KB per 64-deep stage for 2.1 MFLOP: the MFMA work of a stage is a
+// fifth of its fill time), and the double-buffered kernel above keeps ONE stage in flight per CU: the layer then runs at
+// L2-latency x 32 KB (measured 30 GB/s per CU; FC1 208 us for 1 020 rows, 2.7x its per-row time at 10 240 rows). This kernel keeps
+// THREE stages (96 KB) in flight: stage s + 3 is requested as soon as the barrier that opens stage s has shown that everybody
+// left stage s - 1's buffer; each wave waits for its own pieces of stage s with a counted vmcnt (8 / 4 / 0 younger pieces may
+// stay outstanding) and the barrier publishes the other waves' pieces. One barrier per stage. Products per accumulator in the
+// same order as every other tile configuration (stage by stage, k-step 0 then 1), so a row's result does not depend on which
+// kernel -- i.e. which batch size -- computed it (bit-identical, tested).
+// Workgroup -> tile: the 8 XCDs each take a band of column tiles for ALL row tiles (block ids b, b + 8, ... share an XCD), so
+// a weight tile is fetched into ONE L2 and the (small) activation matrix into all of them, instead of the other way round.
+template <typename T, typename TO, bool RELU>
+__global__ __launch_bounds__(kThreads, 2) void gemm_ring_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ W,
+                                                                 int64_t ldw, const float* __restrict__ bias, TO* __restrict__ out,
+                                                                 int64_t ldo, int M, int N, int K, float* __restrict__ partial, int seg,
+                                                                 int osplit) {
+    constexpr int PER = Elem<T>::kPerChunk, KC = Elem<T>::kPerRow;
+    constexpr int kMS = 4, NS = 2, kBM = 128, BN = 128, RING = 4;
+    constexpr int A_BYTES = kBM * kRowBytes, B_BYTES = BN * kRowBytes, STAGE_BYTES = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 15, q = lane >> 4;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (gridDim.y % 8 == 0) {                              // XCD k (block ids = k mod 8) <- column tiles [k n/8, (k + 1) n/8) x all row tiles
+        const int id = blockIdx.x + gridDim.x * blockIdx.y, per = gridDim.y / 8, j = id >> 3;
+        by = (id & 7) * per + j % per;
+        bx = j / per;
+    }
+    const int m0 = bx * kBM, n0 = by * BN;
+    const int abase = tile_off(wm * kMS * 16 + r, q);
+    const int bbase = tile_off(wn * NS * 16 + r, q);
+
+    f32x4 acc[kMS][NS];
+    _Pragma("unroll") for (int i = 0; i < kMS; ++i)
+        _Pragma("unroll") for (int j = 0; j < NS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr uint32_t ESZ = sizeof(T);
+    const int a_rows = M - m0 < kBM ? M - m0 : kBM, w_rows = N - n0 < BN ? N - n0 : BN;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(A) + size_t(m0) * lda, 0,
+                                                                          uint32_t(a_rows) * uint32_t(lda) * ESZ, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(W) + size_t(n0) * ldw, 0,
+                                                                          uint32_t(w_rows) * uint32_t(ldw) * ESZ, 0x00020000);
+    // four 1 KiB pieces per wave and stage (2 of A, 2 of W): rows 8 (wave + 8 p) ..+7, source-side swizzle as in gemm_kernel
+    auto dma = [&](int s, int buf) {
+        int sa = s;
+        if (seg) {
+            const int blk = s / (3 * seg), rr = s - blk * 3 * seg;
+            sa = blk * 2 * seg + (rr < seg ? rr : rr - seg);
+        }
+        char* sA = smem + buf * STAGE_BYTES;
+        char* sB = sA + A_BYTES;
+        const int slot = lane & 7;
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {
+            const int row = 8 * (wave + 8 * p) + (lane >> 3);
+            const int chunk = slot ^ (((row >> 1) & 3) << 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(sA + 8 * (wave + 8 * p) * kRowBytes), 16,
+                                                     int((uint32_t(row) * uint32_t(lda) + chunk * PER) * ESZ), int(sa * KC * ESZ), 0, 0);
+        }
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {
+            const int row = 8 * (wave + 8 * p) + (lane >> 3);
+            const int chunk = slot ^ (((row >> 1) & 3) << 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(sB + 8 * (wave + 8 * p) * kRowBytes), 16,
+                                                     int((uint32_t(row) * uint32_t(ldw) + chunk * PER) * ESZ), int(s * KC * ESZ), 0, 0);
+        }
+    };
+
+    const int all_stages = K / KC;                          // K % KC == 0 (checked by the launcher)
+    const int per_split = (all_stages + int(gridDim.z) - 1) / int(gridDim.z);
+    const int s_begin = int(blockIdx.z) * per_split;
+    const int s_end = s_begin + per_split < all_stages ? s_begin + per_split : all_stages;
+    _Pragma("unroll") for (int p = 0; p < RING - 1; ++p)
+        if (s_begin + p < s_end) dma(s_begin + p, p);
+    for (int s = s_begin; s < s_end; ++s) {
+        const int left = s_end - 1 - s;                     // stages requested after s that may still be in flight (each 4 pieces of this wave)
+        if (left >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (left == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                    // stage s is complete in LDS; nobody reads stage s - 1's buffer any more
+        if (s + RING - 1 < s_end) dma(s + RING - 1, (s - s_begin + RING - 1) % RING);
+        const char* sA = smem + ((s - s_begin) % RING) * STAGE_BYTES;
+        const char* sB = sA + A_BYTES;
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {
+            u32x4 af[kMS], bf[NS];
+            _Pragma("unroll") for (int i = 0; i < kMS; ++i) af[i] = lds_read16(sA, (abase ^ (ks << 6)) + i * 16 * kRowBytes);
+            _Pragma("unroll") for (int j = 0; j < NS; ++j) bf[j] = lds_read16(sB, (bbase ^ (ks << 6)) + j * 16 * kRowBytes);
+            _Pragma("unroll") for (int i = 0; i < kMS; ++i)
+                _Pragma("unroll") for (int j = 0; j < NS; ++j) mma_step<T>(af[i], bf[j], acc[i][j]);
+        }
+    }
+
+    if (partial) {                          // raw sums of this K range; bias / activation happen in the reduction
+        float* pout = partial + size_t(blockIdx.z) * M * N;
+        _Pragma("unroll") for (int j = 0; j < NS; ++j) {
+            const int n = n0 + (wn * NS + j) * 16 + r;
+            if (n >= N) continue;
+            _Pragma("unroll") for (int i = 0; i < kMS; ++i) {
+                const float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {
+                    const int m = m0 + (wm * kMS + i) * 16 + 4 * q + e;
+                    if (m < M) pout[size_t(m) * N + n] = v[e];
+                }
+            }
+        }
+        return;
+    }
+    _Pragma("unroll") for (int j = 0; j < NS; ++j) {
+        const int n = n0 + (wn * NS + j) * 16 + r;
+        if (n >= N) continue;
+        const float b = bias ? bias[n] : 0.f;
+        _Pragma("unroll") for (int i = 0; i < kMS; ++i) {
+            const float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {
+                const int m = m0 + (wm * kMS + i) * 16 + 4 * q + e;
+                if (m < M) {
+                    float y = v[e] + b;
+                    if (RELU) y = fmaxf(y, 0.f);
+                    if (sizeof(TO) == 2 && osplit) {              // [hi(N) | lo(N)] row of 2 N bf16
+                        const float hi = bf2f(f2bf(y));
+                        store_elem<TO>(out + size_t(m) * ldo + n, hi);
+                        store_elem<TO>(out + size_t(m) * ldo + N + n, y - hi);
+                    } else {
+                        store_elem<TO>(out + size_t(m) * ldo + n, y);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // out = act(sum over splits + bias), fixed order
 template <typename TO>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int splits, int64_t M, int N,
@@ -311,6 +445,28 @@ int launch(const void* a, int64_t lda, const void* w, int64_t ldw, const float* 
     hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, static_cast<const T*>(a), lda, static_cast<const T*>(w), ldw,
                        bias, static_cast<TO*>(out), ldo, int(M), int(N), int(K), splits > 1 ? partial : nullptr, seg, osplit);
     MLA_LAUNCH_OK("gemm_kernel");
+    if (splits > 1) {
+        const int64_t total = M * N;
+        hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3(unsigned((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256),
+                           0, s, partial, splits, M, int(N), bias, int(RELU), static_cast<TO*>(out), ldo);
+        MLA_LAUNCH_OK("splitk_reduce_kernel");
+    }
+    return MLA_OK;
+}
+
+template <typename T, typename TO, bool RELU>
+int launch_ring(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* out, int64_t ldo,
+                int64_t M, int64_t N, int64_t K, hipStream_t s, int splits = 1, float* partial = nullptr, int seg = 0, int osplit = 0) {
+    constexpr int lds = 4 * (128 + 128) * kRowBytes;                      // four stages of a 128 x 128 tile: 128 KB
+    MLA_REQUIRE(uint64_t(128) * uint64_t(lda) * sizeof(T) < (1ull << 31) && uint64_t(128) * uint64_t(ldw) * sizeof(T) < (1ull << 31), MLA_E_SHAPE,
+                "GEMM row pitch too large for 32-bit buffer offsets (lda %lld, ldw %lld)", (long long)lda, (long long)ldw);
+    MLA_REQUIRE(K % mma::Elem<T>::kPerRow == 0, MLA_E_SHAPE, "the ring GEMM stages whole %d-element K chunks", mma::Elem<T>::kPerRow);
+    auto kern = gemm_ring_kernel<T, TO, RELU>;
+    MLA_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const dim3 grid{unsigned((M + 127) / 128), unsigned((N + 127) / 128), unsigned(splits)};
+    hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, static_cast<const T*>(a), lda, static_cast<const T*>(w), ldw, bias,
+                       static_cast<TO*>(out), ldo, int(M), int(N), int(K), splits > 1 ? partial : nullptr, seg, osplit);
+    MLA_LAUNCH_OK("gemm_ring_kernel");
     if (splits > 1) {
         const int64_t total = M * N;
         hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3(unsigned((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256),
@@ -366,9 +522,15 @@ int dispatch(const void* a, int64_t lda, const void* w, int64_t ldw, const float
     if (wide) {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (((M + 127) / 128) * ((N + 255) / 256) * 2 <= cus)
+        if (((M + 127) / 128) * ((N + 255) / 256) * 2 <= cus) {
+#if MLA_GEMM_RING
+            if (K % mma::Elem<T>::kPerRow == 0 && K / mma::Elem<T>::kPerRow >= 8)       // long K streamed by few tiles: keep three stages in flight
+                return relu ? launch_ring<T, TO, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit)
+                            : launch_ring<T, TO, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit);
+#endif
             return relu ? launch<T, TO, 4, 2, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit)
                         : launch<T, TO, 4, 2, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit);
+        }
     }
     if (wide) return relu ? launch<T, TO, 4, 4, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit)
                           : launch<T, TO, 4, 4, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, 1, nullptr, seg, osplit);
@@ -407,6 +569,37 @@ extern "C" int mla_linear_splitk(const float* a, int64_t lda, const float* w, in
     hipStream_t s = static_cast<hipStream_t>(stream);
     return relu ? launch<float, float, 4, 2, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, splits, workspace)
                 : launch<float, float, 4, 2, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, splits, workspace);
+}
+
+// Fixed K split for NARROW forward layers (N <= 128 with a long K: VGGish's last Linear 4096 -> 128): with one column tile there
+// are M / 128 workgroups for 256 CUs -- 80 at 10 240 rows, 16 at 1 020 -- each walking all of K. `splits` K ranges (the CALLER
+// fixes the number per layer, never per batch) run as separate workgroups of the four-stage ring kernel; their float32 partial
+// sums are added in range order, then bias and activation. The order of every addition is a function of (K, splits) alone, so
+// a row's result is the same in every batch (what split-K chosen by batch size would break).
+extern "C" int mla_linear_ksplit(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* out, int64_t ldo,
+                                 int64_t M, int64_t N, int64_t K, int dtype, int out_dtype, int relu, int splits, float* workspace,
+                                 int64_t workspace_floats, mla_stream_t stream) {
+    MLA_REQUIRE(M >= 0 && N > 0 && K > 0 && splits >= 1 && splits <= 64, MLA_E_ARG, "bad K-split GEMM arguments");
+    if (M == 0) return MLA_OK;
+    MLA_REQUIRE(a && w && out && workspace, MLA_E_ARG, "null GEMM operand");
+    MLA_REQUIRE(dtype == MLA_F32 || dtype == MLA_BF16, MLA_E_DTYPE, "GEMM dtype %d", dtype);
+    MLA_REQUIRE(out_dtype == MLA_F32 || (out_dtype == MLA_BF16 && dtype == MLA_BF16), MLA_E_DTYPE, "GEMM out dtype %d for compute dtype %d", out_dtype, dtype);
+    const int kc = dtype == MLA_F32 ? 32 : 64;
+    MLA_REQUIRE(K % (int64_t(kc) * splits) == 0 && lda % (kc / 8) == 0 && ldw % (kc / 8) == 0 && lda >= K && ldw >= K && ldo >= N, MLA_E_SHAPE,
+                "K-split GEMM: K %lld must be a multiple of %d x splits %d (whole stages per range)", (long long)K, kc, splits);
+    MLA_REQUIRE(mla::aligned(a, 16) && mla::aligned(w, 16), MLA_E_ARG, "GEMM operands must be 16-byte aligned");
+    MLA_REQUIRE(workspace_floats >= int64_t(splits) * M * N, MLA_E_ARG, "K-split workspace too small");
+    MLA_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), MLA_E_SHAPE, "GEMM dimension overflow");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool r = relu != 0;
+    if (dtype == MLA_F32)
+        return r ? launch_ring<float, float, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, splits, workspace)
+                 : launch_ring<float, float, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, splits, workspace);
+    if (out_dtype == MLA_F32)
+        return r ? launch_ring<mma::bf16_t, float, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, splits, workspace)
+                 : launch_ring<mma::bf16_t, float, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, splits, workspace);
+    return r ? launch_ring<mma::bf16_t, mma::bf16_t, true>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, splits, workspace)
+             : launch_ring<mma::bf16_t, mma::bf16_t, false>(a, lda, w, ldw, bias, out, ldo, M, N, K, s, splits, workspace);
 }
 
 extern "C" int mla_linear(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* out,

@@ -149,6 +149,9 @@ def conv(layer, x, w_packed, b, split=False):
     return out
 
 
+KSPLIT = 8          # fixed K ranges of the narrow forward layers (see linear)
+
+
 def linear(a, w, b, relu=False, out_dtype=None, out=None, split_k=False):
     """a (M, K), w (N, K) same dtype (f32 | bf16), bias f32 -> (M, N) (optionally into `out`). split_k: allow K to be split
     over workgroups when there are few output tiles (weight gradients). Forward layers never split: the number of splits
@@ -168,6 +171,18 @@ def linear(a, w, b, relu=False, out_dtype=None, out=None, split_k=False):
             and a.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0):
         _lib.check(_timed("linear_%dx%d" % (K, N), _lib.lib().mla_linear_narrow, _p(a), a.stride(0), _p(w), w.stride(0), _p(b), _p(out), N,
                           M, N, K, _lib.stream_ptr()))
+        return out
+    # narrow forward layers with a long reduction (VGGish's Linear(4096, 128): one column tile, so M / 128 workgroups for 256 CUs):
+    # K always runs as KSPLIT fixed ranges whose partial sums are added in range order -- a per-LAYER constant, so a row's result
+    # is the same in every batch (a split chosen by batch size would change the summation order)
+    kc = 64 if a.dtype == torch.bfloat16 else 32
+    if N <= 128 and K >= 2048 and K % (kc * KSPLIT) == 0 and not split_k and a.stride(0) % 8 == 0 and w.stride(0) % 8 == 0:
+        key = "ksplit/" + str(a.device)
+        if key not in _ws or _ws[key].numel() < KSPLIT * M * N:
+            _ws[key] = torch.empty(max(KSPLIT * M * N, 1 << 22), dtype=torch.float32, device=a.device)
+        ws = _ws[key]
+        _lib.check(_timed("linear_%dx%d" % (K, N), _lib.lib().mla_linear_ksplit, _p(a), a.stride(0), _p(w), w.stride(0), _p(b), _p(out), N,
+                          M, N, K, DT[a.dtype], DT[out_dtype], int(relu), KSPLIT, _p(ws), ws.numel(), _lib.stream_ptr()))
         return out
     # few output tiles but a long reduction (weight gradients): split K over workgroups
     tiles = ((M + 127) // 128) * ((N + 127) // 128)

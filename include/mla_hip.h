@@ -165,6 +165,13 @@ int mla_vggish_conv(int layer, const void* in, const void* w_repacked, const flo
 int mla_linear(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* out,
                int64_t ldo, int64_t M, int64_t N, int64_t K, int dtype, int out_dtype, int relu,
                mla_stream_t stream);
+/* mla_linear for NARROW forward layers with a long reduction (vggish.py:17: Linear(4096, 128)): K is cut into `splits` equal
+ * ranges of whole 128-byte stages that run as separate workgroups; the float32 partial sums (workspace: splits * M * N floats)
+ * are added in range order, then bias / ReLU. The caller fixes `splits` per LAYER, never per batch: every addition's order
+ * depends on (K, splits) only, so a row's result does not depend on the batch it is computed in. f32 or bf16 operands. */
+int mla_linear_ksplit(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* out, int64_t ldo,
+                      int64_t M, int64_t N, int64_t K, int dtype, int out_dtype, int relu, int splits, float* workspace,
+                      int64_t workspace_floats, mla_stream_t stream);
 /* mla_linear in f32 with the reduction dimension split over `splits` workgroup ranges (weight
  * gradients: few output tiles, K = batch rows); partial sums go through workspace
  * (splits * M * N floats) and are combined in fixed order. */

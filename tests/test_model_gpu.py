@@ -387,3 +387,29 @@ def test_tall_and_wide_conv_tiles_are_bit_identical(ops, vg, W):
             os.environ.pop("MLA_CONV_TILE", None)
             feats.precision = "f32"
         assert tall3.shape[-1] == 1024 and torch.equal(tall3.view(torch.int16), wide3.view(torch.int16)), "bf16x3, %d clips" % n
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_ring_and_ksplit_gemms_do_not_depend_on_the_batch(ops, W, dtype):
+    """Forward Linear layers pick their kernel by batch size: 320 x 256 / 256 x 256 tiles for thousands of rows, the four-stage
+    ring of 128 x 128 tiles when few tiles stream a long K (about 1 000 rows), and for narrow layers (N <= 128, long K) the ring
+    kernel over KSPLIT fixed K ranges whose partial sums are added in range order. A row's result must be the same bits whichever
+    kernel its batch selects (model.py:61 makes no promise about batch composition; tests/test_model_gpu.py
+    test_full_size_forward_properties checks the whole pipeline, this one the kernels with tails)."""
+    M, K = 4200, 2048
+    a = torch.from_numpy(W.uniform(71, 1, M * K, lo=-1.0, hi=1.0)).reshape(M, K).cuda()
+    for N in (1024, 128):
+        w = (torch.from_numpy(W.uniform(71, 2 + N, N * K)).reshape(N, K) * (3.0 / K) ** 0.5).cuda()
+        b = torch.from_numpy(W.uniform(71, 3, N)).cuda()
+        if dtype == "bf16":
+            aa, ww = ops.to_bf16(a), ops.to_bf16(w)
+        else:
+            aa, ww = a, w
+        full = ops.linear(aa, ww, b, relu=True, out_dtype=torch.float32)
+        ref = F.relu(F.linear(aa.float().double(), ww.float().double(), b.double()))
+        assert rel_err(full.cpu(), ref.cpu()) < 2e-5
+        for rows in (1, 130, 1020, 2049):
+            part = ops.linear(aa[:rows].contiguous(), ww, b, relu=True, out_dtype=torch.float32)
+            assert torch.equal(part, full[:rows]), (N, rows)
+        shifted = ops.linear(aa[77:77 + 1020].contiguous(), ww, b, relu=True, out_dtype=torch.float32)
+        assert torch.equal(shifted, full[77:77 + 1020]), N
