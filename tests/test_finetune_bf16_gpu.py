@@ -286,3 +286,64 @@ def test_window_codes_route_gradients_like_the_prepool_activation(shape):
     assert torch.equal(win(dz_a), win(dz_c)) and torch.equal(db_a, db_c)              # same gradient mass per window, same bias gradient
     differ = float((dz_a != dz_c).float().mean())
     assert differ < 5e-3, differ
+
+
+def test_config4_full_size_finetune_bf16_is_deterministic_and_shards(tmp_path, mk, W):
+    """BASELINE config 4 at its literal size in the finetune variant (train.py:96-97: every parameter trainable): the step on
+    512 bags (5 120 clips of 96 x 64 log-mel), CNN in bf16 with f32 master weights, the configuration bench.py's train_step leg
+    times. Size-independent properties (the CPU reference cannot run this in seconds):
+    (1) two runs give identical bits -- losses, hit counts, every updated parameter;
+    (2) two ranks with 256 bags each (gloo, sharing the test GPU; SyncBN sums + the five gradient buckets on the second
+        stream) stay bit-identical replicas and reproduce the one-process run: the first loss to float32 rounding of the
+        statistics' summation tree; the second, after one Adam step of +-lr on 73 M weights whose small gradients change sign
+        with the summation order of the two half-batch weight gradients, to 2e-3."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    TR = importlib.import_module(PKG + ".train")
+    M = importlib.import_module(PKG + ".model")
+    B, steps = 512, 2
+
+    def install(ens, masks):
+        for lvl, em in enumerate(ens.mla.embedded_mappings):
+            for j, d in enumerate(em.dropouts):
+                d.mask = masks["mla.embedded_mappings.%d.dropouts.%d" % (lvl, j)]
+
+    def one_process():
+        ens = M.Ensemble("repeat", dict(mk.CNN_CONF), [2, 1], torch.device("cuda"), precision="bf16")
+        ens.load_state_dict({k: torch.as_tensor(v) for k, v in W.make_state_dict(7, W.ensemble_shapes((2, 1), False)).items()})
+        ens.cuda()
+        M.set_requires_grad(ens, True)
+        step = TR.TrainStep(ens, lr=1e-3)
+        losses, hits_all = [], []
+        for s in range(steps):
+            x, y = mk.synth_bags(100 + s, B)
+            install(ens, mk.make_masks(200 + s, [2, 1], B))
+            loss, hits = step(x.cuda(), y.cuda())
+            losses.append(float(loss)); hits_all.append(hits.tolist())
+        return losses, hits_all, step.flat_p.clone()
+
+    l1, h1, p1 = one_process()
+    torch.cuda.empty_cache()
+    l2, h2, p2 = one_process()
+    assert l1 == l2 and h1 == h2 and torch.equal(p1, p2), "the bf16 finetune step must be bit-deterministic at full size"
+    assert all(np.isfinite(l1)) and abs(l1[0] - np.log(10.0)) < 0.2 and all(0 <= h[0] <= B and h[1] == 0 for h in h1)
+    del p1, p2
+    torch.cuda.empty_cache()
+
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "dpft512")
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_worker.py"), out, str(steps), str(B), "bf16", "finetune"],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=1200) == 0
+    r0, r1 = np.load(out + ".rank0.npz"), np.load(out + ".rank1.npz")
+    for k in r0.files:
+        np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)                    # replicas: bit-identical, CNN biases included
+    assert any(k.startswith("cnn.") for k in r0.files)
+    np.testing.assert_allclose(r0["losses"][:1], l1[:1], rtol=2e-6, atol=0)
+    np.testing.assert_allclose(r0["losses"], l1, rtol=2e-3, atol=0)
+    print("config 4 finetune bf16, 2 ranks vs 1 process: losses %s vs %s" % (r0["losses"], l1))
