@@ -577,11 +577,34 @@ def load_pmc_traffic():
     """HBM bytes per clip of the dominant kernels, from rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate
     passes (profiles/r02_pmc_traffic.json, written by scripts/profile_traffic.sh). PMC counters cannot be read from inside
     this process; per-launch traffic = per-clip figure x the clips of this launch (both kernels stream per clip)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.exists(path):
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))       # the newest round's file
+    if not paths:
         return {}
-    with open(path) as f:
-        return json.load(f)
+    with open(paths[-1]) as f:
+        d = json.load(f)
+    d["_file"] = os.path.basename(paths[-1])
+    return d
+
+
+PEAK_CLOCK_GHZ, N_SIMD, N_CU = 2.4, 1024, 256        # MI355X_MICROARCH.md: max clock, 256 CUs x 4 SIMD-32
+
+
+def frontend_issue_bound(t_fe, clips, launch_s):
+    """The bound that actually binds the log-mel kernel (its HBM traffic is 1.00x the algorithmic bytes at 0.3 of the HBM peak):
+    vector-instruction issue and the LDS array. From the PMC pass on file (scripts/profile_traffic.sh, third pass):
+    wave-instructions per clip x clips of this launch. A SIMD-32 issues one wave64 vector instruction per 2 cycles at best
+    (MI355X_MICROARCH.md, wave scheduling; transcendentals take longer, so this is a LOWER bound on the time); the LDS array
+    serves one access cycle per CU and clock. Both priced at the 2.4 GHz peak clock; `frac` = bound / measured launch time."""
+    if not t_fe or "issue" not in t_fe:
+        return None
+    i = t_fe["issue"]
+    valu_s = i["valu_insts_per_clip"] * clips * 2.0 / (N_SIMD * PEAK_CLOCK_GHZ * 1e9)
+    lds_s = i["lds_array_cycles_per_clip"] * clips / (N_CU * PEAK_CLOCK_GHZ * 1e9)
+    return {"valu_insts_per_clip": i["valu_insts_per_clip"], "valu_bound_ms": valu_s * 1e3, "frac_of_valu_bound": valu_s / launch_s,
+            "lds_array_cycles_per_clip": i["lds_array_cycles_per_clip"], "lds_bound_ms": lds_s * 1e3, "frac_of_lds_bound": lds_s / launch_s,
+            "lds_conflict_share": i["lds_conflict_cycles_per_clip"] / i["lds_array_cycles_per_clip"] if i["lds_array_cycles_per_clip"] else None,
+            "clock_GHz_while_profiled": i.get("clock_GHz_while_profiled"), "source": i["source"]}
 
 
 def infer_mode(args, world, rank, device, ops):
@@ -656,7 +679,8 @@ def infer_mode(args, world, rank, device, ops):
             "roofline_frontend": {"bound": "hbm", "kernel": "logmel_dyn_kernel", "achieved": fe_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                   "frac": fe_gbps / PEAK_HBM_GBPS, "avg_launch_ms": avg["logmel"] * 1e3,
                                   "bytes_per_clip": FE_BYTES[fe_dtype],
-                                  "traffic": t_fe["bytes_per_clip"] * clips_per_step if t_fe else None},
+                                  "traffic": t_fe["bytes_per_clip"] * clips_per_step if t_fe else None,
+                                  "issue": frontend_issue_bound(t_fe, clips_per_step, avg["logmel"])},
             "kernel_ms": {k: round(v * 1e3, 4) for k, v in sorted(avg.items())},
         }
         def leg(name, fn):

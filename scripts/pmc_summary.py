@@ -5,7 +5,7 @@ import collections, csv, glob, re, sys
 
 
 def short(name):
-    m = re.search(r"(conv3x3_kernel|conv1_kernel|conv1_patch_kernel|gemm_kernel|logmel_kernel|logmel_dyn_kernel|wgrad_bf16_kernel|wgrad_kernel)<(.*?)>\s*\(", name)
+    m = re.search(r"(conv3x3_kernel|conv1_kernel|conv1_patch_kernel|gemm_ring_kernel|gemm_kernel|logmel_kernel|logmel_dyn_kernel|wgrad_bf16_kernel|wgrad_kernel)<(.*?)>\s*\(", name)
     if not m:
         return None
     cfg = m.group(2).replace("(anonymous namespace)::", "").replace("mma::bf16_t", "bf16").replace("__hip_bfloat16", "bf16")

@@ -43,6 +43,10 @@ def test_one_gpu_line_has_the_contract_fields_and_consistent_numbers():
     v = d["value_at_tolerance"]
     assert v["mode"] in ("bf16x3", "f32") and v["measured_max_rel"] <= v["tolerance"] == 1e-4
     assert d["roofline_frontend"]["bound"] == "hbm" and 0 < d["roofline_frontend"]["frac"] < 1
+    # the bound that binds the front-end (vector issue, LDS array), from the PMC pass on file x the clips of this launch
+    i = d["roofline_frontend"]["issue"]
+    assert 10000 < i["valu_insts_per_clip"] < 25000 and 0 < i["frac_of_valu_bound"] < 1 and 0 < i["frac_of_lds_bound"] < 1
+    assert abs(i["valu_bound_ms"] - i["valu_insts_per_clip"] * clips * 2 / (1024 * 2.4e9) * 1e3) < 1e-9
 
 
 def test_two_self_launched_ranks_report_the_aggregate_and_the_data_parallel_train_step():

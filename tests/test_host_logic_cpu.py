@@ -64,7 +64,8 @@ def test_resampling_filter_is_the_restated_kaiser_best_design():
 
 
 def test_pmc_traffic_file_feeds_the_bench_line():
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    import glob
+    path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))[-1]     # bench.py reads the newest round's file
     d = json.load(open(path))
     for key in ("conv2/bf16", "conv3/bf16", "conv4/bf16", "conv5/bf16", "conv6/bf16", "logmel/bf16"):
         assert d[key]["bytes_per_clip"] > 0 and "FETCH_SIZE" in d[key]["source"] and "WRITE_SIZE" in d[key]["source"]
