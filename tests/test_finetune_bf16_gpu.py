@@ -347,3 +347,52 @@ def test_config4_full_size_finetune_bf16_is_deterministic_and_shards(tmp_path, m
     np.testing.assert_allclose(r0["losses"][:1], l1[:1], rtol=2e-6, atol=0)
     np.testing.assert_allclose(r0["losses"], l1, rtol=2e-3, atol=0)
     print("config 4 finetune bf16, 2 ranks vs 1 process: losses %s vs %s" % (r0["losses"], l1))
+
+
+def test_composed_bf16_backward_against_float64_autograd_on_the_same_activations(W):
+    """The whole bf16 CNN backward (cnn_train.backward: pool / ReLU backward from window codes, wgrad, dgrad, conv1's MFMA backward,
+    the three Linear layers) composed, against torch autograd in float64 whose forward is FORCED onto the GPU's own bf16 activations
+    (straight-through: every layer output is replaced by the value the HIP forward produced, gradients flow through the float64 graph)
+    and whose weights are the bf16-rounded ones. What remains different is f32 accumulation order and the bf16 storage of the
+    gradient tensors between layers -- no routing, indexing or layer-wiring error can hide: per parameter tensor the relative L2
+    error must stay below 1e-2 (measured: printed) where the end-to-end check against the f32 path only asks for cosine 0.95."""
+    cnn_train = importlib.import_module(PKG + ".cnn_train")
+    V = importlib.import_module(PKG + ".torchvggish.vggish")
+    n = 3
+    vg = V.VGGish(urls={}, pretrained=False, preprocess=False, postprocess=False, precision="bf16")
+    sd = W.make_state_dict(1, W.vggish_shapes())
+    vg.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    vg.cuda()
+    x = torch.from_numpy(W.uniform(91, 1, n * 96 * 64, lo=-1.4, hi=4.6)).reshape(n, 96, 64)
+    d_out = torch.from_numpy(W.uniform(91, 2, n * 128, lo=-1.0, hi=1.0)).reshape(n, 128)
+    with torch.no_grad():
+        emb, tape = cnn_train.forward(vg, x.cuda(), "bf16")
+        grads = {k: torch.zeros_like(p, dtype=torch.float32) for k, p in vg.named_parameters()}
+        cnn_train.backward(vg, tape, d_out.cuda(), grads, "")
+    # float64 reference on the GPU's activations
+    conv_idx, pooled = [0, 3, 6, 8, 11, 13], {0, 3, 8, 13}
+    params = {k: bf(torch.as_tensor(v)).double().requires_grad_(k.endswith("weight")) if k.endswith("weight")
+              else torch.as_tensor(v).double().requires_grad_(True) for k, v in sd.items()}
+    nhwc_to_nchw = lambda t: t.double().permute(0, 3, 1, 2).cpu()
+    h = bf(x).double()[:, None]
+    layer_inputs = {2: tape["layers"][2][0], 3: tape["layers"][3][0], 4: tape["layers"][4][0], 5: tape["layers"][5][0], 6: tape["layers"][6][0]}
+    for li, idx in enumerate(conv_idx):
+        z = F.relu(F.conv2d(h, params["features.%d.weight" % idx], params["features.%d.bias" % idx], padding=1))
+        if idx in pooled:
+            z = F.max_pool2d(z, 2, 2)
+        gpu = nhwc_to_nchw(layer_inputs[li + 2]) if li + 2 <= 6 else nhwc_to_nchw(tape["fc"][0][0].reshape(n, 6, 4, 512))
+        assert float((z.detach() - gpu).abs().max()) <= 2e-2 * float(gpu.abs().max()) + 1e-3, idx     # the forwards agree to bf16 rounding
+        h = z + (gpu - z).detach()
+    h = h.permute(0, 2, 3, 1).reshape(n, -1)
+    for i, idx in enumerate((0, 2, 4)):
+        z = F.relu(F.linear(h, params["embeddings.%d.weight" % idx], params["embeddings.%d.bias" % idx]))
+        gpu = (tape["fc"][i][1] if i < 2 else emb).double().cpu()
+        h = z + (gpu - z).detach()
+    h.backward(d_out.double())
+    worst = 0.0
+    for k, g_gpu in grads.items():
+        ref = params[k].grad
+        err = float((g_gpu.cpu().double() - ref).norm() / (ref.norm() + 1e-30))
+        worst = max(worst, err)
+        assert err < 1e-2, (k, err)
+    print("composed bf16 backward vs float64 autograd on the same activations: worst relative L2 error %.3g" % worst)
