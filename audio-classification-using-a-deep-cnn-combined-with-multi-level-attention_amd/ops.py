@@ -283,24 +283,44 @@ class Dist:
         always = (os.environ.get("MLA_DIST_ALWAYS") == "1") if always is None else always
         self.active = inited and (self.world > 1 or always)
         self.via = None
+        self.fallback = None
         if self.active and self.backend == "nccl":
             self.via = os.environ.get("MLA_DIST_COLLECTIVE", "abi")
             if self.via == "abi":
-                self._init_comm(dist)
+                # every rank tries; the ranks then agree (one MIN all-reduce through torch.distributed) on whether ALL of them have a
+                # communicator. If one could not make it (an RCCL without the entry points the library binds, a failed init), all of
+                # them switch to torch.distributed.all_reduce on the same device buffers and say so (describe()["fallback"]): a
+                # data-parallel run never ends up with ranks on different transports.
+                err = None
+                try:
+                    self._init_comm(dist)
+                except Exception as e:                      # noqa: BLE001 -- reported through describe(), the run continues on torch's transport
+                    err = "%s: %s" % (type(e).__name__, e)
+                ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+                if int(ok.item()) == 0:
+                    self.close()
+                    self.via = "torch"
+                    self.fallback = err or "another rank could not create its communicator through the C ABI"
         elif self.active:
             self.via = "host"
 
     def _init_comm(self, dist):
         dev = torch.device("cuda", torch.cuda.current_device())
-        uid = torch.zeros(128, dtype=torch.uint8)
+        uid, err0 = torch.zeros(128, dtype=torch.uint8), None
         if self.rank == 0:
             buf = (ctypes.c_char * 128)()
-            _lib.check(_lib.lib().mla_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
-            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            try:
+                _lib.check(_lib.lib().mla_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+                uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            except Exception as e:                          # noqa: BLE001 -- the other ranks are waiting in the broadcast below: send them zeros
+                err0 = e
         uid = uid.to(dev)
         src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
         dist.broadcast(uid, src=src, group=self.group)
         raw = bytes(uid.cpu().numpy().tobytes())
+        if err0 is not None or not any(raw):
+            raise err0 or RuntimeError("rank 0 could not obtain an RCCL unique id through the C ABI")
         comm = ctypes.c_void_p()
         _lib.check(_lib.lib().mla_comm_init_rank(ctypes.byref(comm), self.world, ctypes.c_char_p(raw), self.rank))
         self.comm = comm
@@ -371,7 +391,8 @@ class Dist:
         origin = _lib.lib().mla_comm_library_origin().decode() if self.via == "abi" else None
         return {"active": bool(self.active), "backend": self.backend, "transport": {"abi": "mla_allreduce_flat (C ABI -> ncclAllReduce)",
                 "torch": "torch.distributed.all_reduce", "host": "torch.distributed.all_reduce through host copies (gloo rehearsal)",
-                None: None}[self.via], "rccl_library_origin": origin, "ranks": self.ranks_reported(), "sync_bn": bool(self.sync_bn)}
+                None: None}[self.via], "rccl_library_origin": origin, "ranks": self.ranks_reported(), "sync_bn": bool(self.sync_bn),
+                "fallback": getattr(self, "fallback", None)}
 
 
 LOCAL = None          # set lazily (torch.distributed may not be initialised at import time)
@@ -382,7 +403,7 @@ def _local():
     if LOCAL is None:
         LOCAL = Dist.__new__(Dist)
         LOCAL.group, LOCAL.world, LOCAL.rank, LOCAL.active, LOCAL.comm, LOCAL.via = None, 1, 0, False, None, None
-        LOCAL.sync_bn, LOCAL.trace, LOCAL.backend = True, None, None
+        LOCAL.sync_bn, LOCAL.trace, LOCAL.backend, LOCAL.fallback = True, None, None, None
     return LOCAL
 
 
