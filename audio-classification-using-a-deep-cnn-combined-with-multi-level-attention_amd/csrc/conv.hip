@@ -60,6 +60,11 @@ __device__ unsigned long long g_conv_stamps[8][2][8];
 #ifndef MLA_CONV_PRIO
 #define MLA_CONV_PRIO 3             // 3 (shipped): burst priorities 3 / 2 / 1 / 0 so that no MFMA burst is preempted; 1: waves 4-7 static prio 1; 0: none
 #endif
+#ifndef MLA_CONV_DGRAD2
+#define MLA_CONV_DGRAD2 2           // dgrad conv2 (128 -> 64 @48x32, bf16) tile: 0 = 192 px x 64 ch (2 x 4 waves, NS 1), two workgroups per CU;
+                                    // 1 = 384 px x 64 ch (4 x 2 waves, NS 2), two workgroups per CU; 2 = the same tile as ONE persistent workgroup
+                                    // per CU (LDS-DMA patches, staggered wave pairs). Same device, 5 120 images: 1.38 / 1.69 / 1.15 ms -> 2 (bit-identical)
+#endif
 #ifndef MLA_CONV_NARROW_PERSIST
 #define MLA_CONV_NARROW_PERSIST 0   // 1: conv2's bf16 inference configuration as one persistent workgroup per CU (A/B builds)
 #endif
@@ -131,7 +136,8 @@ struct Cfg {
     static constexpr int A_BYTES = (A_PIX + 7) / 8 * 8 * kRowBytes;   // padded to whole 1 KiB LDS-DMA pieces
     static constexpr int B_BYTES = BN * kRowBytes;
     static constexpr int TILES_Y = H / TH;
-    static constexpr bool PERSIST = NS > 2 || SPLIT || (MLA_CONV_NARROW_PERSIST && sizeof(T) == 2 && NS == 2 && POOL_ && ACT_);        // conv2 (half-width tile): two non-persistent workgroups per CU
+    static constexpr bool PERSIST = NS > 2 || SPLIT || (MLA_CONV_NARROW_PERSIST && sizeof(T) == 2 && NS == 2 && POOL_ && ACT_) ||
+                                    (MLA_CONV_DGRAD2 == 2 && sizeof(T) == 2 && NS == 2 && WM_ == 4 && !ACT_ && COUT_ == 64);        // conv2 (half-width tile): two non-persistent workgroups per CU
                                                             // (its split form has a 3x longer K loop and more epilogue registers)
     static constexpr int MIN_WAVES = (PERSIST || sizeof(T) == 4) ? 2 : 4;      // waves per SIMD the register budget is held to
     static constexpr bool A_DMA = PERSIST;                  // input patches by LDS-DMA into two alternating buffers (else: one
@@ -1025,6 +1031,12 @@ int conv_generic(const void* in, const void* w, const float* bias, void* out, in
     MLA_CONV_CASE_TALL8(512, 256, 12, 8, false, 4, false)       // dgrad conv5
     MLA_CONV_CASE_TALL(256, 256, 24, 16, false, 4, false) // dgrad conv4
     MLA_CONV_CASE_TALL(256, 128, 24, 16, false, 2, false) // dgrad conv3
+#if MLA_CONV_DGRAD2 >= 1
+    // dgrad conv2 (128 -> 64 @48x32), bf16: the tall tile 384 pixels x 64 channels (waves 4 x 2, NS = 2), two workgroups per CU
+    if (cin == 128 && cout == 64 && H == 48 && W == 32 && !pool && !act) {
+        if constexpr (sizeof(T) == 2) return launch_conv<Cfg<T, 128, 64, 48, 32, false, 2, false, false, 4>>(in, w, bias, out, n, s, prepool, codes);
+    }
+#endif
     MLA_CONV_CASE(128, 64, 48, 32, false, 1, false)       // dgrad conv2
 #undef MLA_CONV_CASE_TALL
 #undef MLA_CONV_CASE_TALL8
