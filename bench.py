@@ -113,24 +113,25 @@ def cpu_baseline(ens_sd, gpu_model, device, budget_s=15.0):
 
 
 def small_batch_leg(ens, rank, device, bags=102, steps=50):
-    """BASELINE config 3 read literally ("batch 1024 clips"): 102 bags = 1 020 clips per step, where one step is
-    ~1.5 ms of GPU work behind ~45 launches. Timed eagerly and as one HIP-graph replay per step."""
+    """BASELINE config 3 read literally ("batch 1024 clips"): 102 bags = 1 020 clips per step, ~1.45 ms of GPU work behind ~45
+    launches, timed eagerly. (Rounds 1-2 also timed one HIP-graph replay per step: it measured 1-3 % SLOWER than eager at this size
+    -- the step is bound by kernel time, not by launches -- and was dropped from the line; Ensemble.capture_waveforms stays for
+    batches small enough to be launch-bound and is checked here for bit-identity with the eager result.)"""
     pcm = synth_pcm(bags, rank, device)
     out = {"clips_per_step": bags * T_BAG}
     with torch.no_grad():
         g = ens.capture_waveforms(pcm)
         ref = ens.forward_waveforms(pcm).clone()
         assert torch.equal(g(pcm), ref), "graph replay must reproduce the eager result"
-        for name, fn in (("eager", lambda: ens.forward_waveforms(pcm)), ("hip_graph", lambda: g(pcm))):
-            for _ in range(5):
-                fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                fn()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / steps
-            out[name] = {"ms_per_step": dt * 1e3, "clips_per_s": bags * T_BAG / dt}
+        for _ in range(5):
+            ens.forward_waveforms(pcm)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ens.forward_waveforms(pcm)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out["eager"] = {"ms_per_step": dt * 1e3, "clips_per_s": bags * T_BAG / dt}
     return out
 
 
