@@ -20,7 +20,7 @@ all-reduce. This module trades that for the reference's calling convention.
 
 Not reproduced: the gradient with respect to the input examples (``waveform_to_examples`` returns a tensor with
 ``requires_grad=True``, vggish_input.py:79-80; the reference computes that gradient and never reads it) -- the conv stack's
-Function returns ``None`` for it.
+Function returns ``None`` for it. Train and eval mode are both differentiable (eval: BatchNorm with its running statistics).
 """
 
 import torch
@@ -100,8 +100,9 @@ class CastFn(torch.autograd.Function):
 
 
 class HeadFn(torch.autograd.Function):
-    """apply(mla, x, *parameters of mla in named_parameters() order): x (B, T, M) float32 -> (B, K) sigmoid scores; train-mode
-    BatchNorm (batch statistics, running buffers updated) and Dropout, as ``MultiLevelAttention.forward`` in training."""
+    """apply(mla, x, *parameters of mla in named_parameters() order): x (B, T, M) float32 -> (B, K) sigmoid scores, in the module's
+    current mode: train (BatchNorm batch statistics, running buffers updated, Dropout) or eval (running statistics, no dropout);
+    the backward differentiates the forward that ran."""
 
     @staticmethod
     def forward(ctx, mla, x, *params):

@@ -17,6 +17,7 @@ class Ctx:
         self.tape = [] if tape else None
         self.dist = dist or ops._local()
         self.counter, self.bases = counter, bases
+        self.train = True
 
 
 def _bn_stats(bn, z, mode, period, train, ctx):
@@ -77,6 +78,7 @@ def attention_forward(am, h, y, ctx=None, level=0):
 def mla_forward(mla, x, ctx=None):
     """model.py:258-269: x (B, T, M) -> (B, K) sigmoid scores."""
     ctx = ctx or Ctx()
+    ctx.train = mla.training                 # batch statistics + dropout (train) or running statistics (eval): the backward must match
     B = x.shape[0]
     L = len(mla.model)
     conc = torch.empty((B, L * K), dtype=torch.float32, device=x.device)
@@ -119,9 +121,12 @@ def mla_backward(mla, ctx, dout, grads, need_input_grad=False):
     relative to `mla` (e.g. 'embedded_mappings.0.fc.1.weight') to preallocated gradient tensors,
     all of which are overwritten. Returns d(loss)/dx (B*T, M) if need_input_grad."""
     tape, dist = ctx.tape, ctx.dist
+    bs = ctx.train                           # eval-mode forward: fixed (running) statistics, no dropout scale
+    drop = 1.0 / (1.0 - DR) if bs else 1.0
     kind, _, conc, z, mean, var, out = tape[-1]
     assert kind == "head"
-    dz = ops.bn_backward(z, dout, out, 2, 1.0, 1, 0, mean, var, mla.norm.weight.detach(), dist, grads["norm.weight"], grads["norm.bias"])
+    dz = ops.bn_backward(z, dout, out, 2, 1.0, 1, 0, mean, var, mla.norm.weight.detach(), dist, grads["norm.weight"], grads["norm.bias"],
+                         batch_stats=bs)
     dconc = ops.linear_small_bwd(conc, mla.fc.weight.detach(), dz, grads["fc.weight"], grads["fc.bias"])
 
     # split the tape per level
@@ -138,9 +143,10 @@ def mla_backward(mla, ctx, dout, grads, need_input_grad=False):
         _, am, _, h_rows, z_att, nv, nf, att, cla = entries[-1]
         pa = "attention_modules.%d." % lvl
         du_v, du_f = ops.attention_pool_bwd(dconc[:, lvl * K:(lvl + 1) * K], att, cla, B, T, K)
-        dz_att = ops.bn_backward(z_att, du_v, None, 0, 1.0, 0, T, nv[0], nv[1], nv[2], dist, grads[pa + "normv.weight"], grads[pa + "normv.bias"])
+        dz_att = ops.bn_backward(z_att, du_v, None, 0, 1.0, 0, T, nv[0], nv[1], nv[2], dist, grads[pa + "normv.weight"], grads[pa + "normv.bias"],
+                                 batch_stats=bs)
         ops.bn_backward(z_att, du_f, None, 0, 1.0, 0, T, nf[0], nf[1], nf[2], dist, grads[pa + "normf.weight"], grads[pa + "normf.bias"],
-                        dx=dz_att, accumulate=True)
+                        dx=dz_att, accumulate=True, batch_stats=bs)
         dh = _linear_backward(h_rows, am.fcv.weight.detach(), dz_att, grads[pa + "fcv.weight"], grads[pa + "fcv.bias"], True)
         if dh_next is not None:
             ops.axpy(1.0, dh_next, dh)
@@ -148,11 +154,11 @@ def mla_backward(mla, ctx, dout, grads, need_input_grad=False):
         pe = "embedded_mappings.%d." % lvl
         for e in reversed(entries[1:-1]):
             _, _, j, h_in, z_j, mean_j, var_j, h_out = e
-            dzj = ops.bn_backward(z_j, dh, h_out, 1, 1.0 / (1.0 - DR), 0, T, mean_j, var_j, em.norms[j].weight.detach(), dist,
-                                  grads[pe + "norms.%d.weight" % j], grads[pe + "norms.%d.bias" % j])
+            dzj = ops.bn_backward(z_j, dh, h_out, 1, drop, 0, T, mean_j, var_j, em.norms[j].weight.detach(), dist,
+                                  grads[pe + "norms.%d.weight" % j], grads[pe + "norms.%d.bias" % j], batch_stats=bs)
             dh = _linear_backward(h_in, em.fc[j].weight.detach(), dzj, grads[pe + "fc.%d.weight" % j], grads[pe + "fc.%d.bias" % j], True)
         _, _, rows_in, mean0, var0 = entries[0]
         want = lvl > 0 or need_input_grad
         dh_next = ops.bn_backward(rows_in, dh, None, 0, 1.0, 0, T, mean0, var0, em.norm0.weight.detach(), dist,
-                                  grads[pe + "norm0.weight"], grads[pe + "norm0.bias"], want_dx=want)
+                                  grads[pe + "norm0.weight"], grads[pe + "norm0.bias"], want_dx=want, batch_stats=bs)
     return dh_next

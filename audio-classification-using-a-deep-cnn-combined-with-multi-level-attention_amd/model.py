@@ -279,10 +279,9 @@ class MultiLevelAttention(nn.Module):
         self.norm = BatchNorm1d(K)
 
     def forward(self, x):
-        if self.training and differentiable.wants_grad(self, x):
-            # train.py:124-138 on the drop-in: outputs = clf(inputs); loss.backward() -- the head's HIP backward runs behind autograd.
-            # (eval mode with gradients enabled is not differentiable here: the reference's loop evaluates under
-            # torch.set_grad_enabled(False), train.py:128.)
+        if differentiable.wants_grad(self, x):
+            # train.py:124-138 on the drop-in: outputs = clf(inputs); loss.backward() -- the head's HIP backward runs behind autograd,
+            # in train mode (batch statistics, dropout) and in eval mode (running statistics) alike
             return differentiable.HeadFn.apply(self, x.float(), *self.parameters())
         return mla_train.mla_apply(self, x)
 

@@ -441,9 +441,10 @@ def bn_stats_sync(x, mode, period, dist, running_mean=None, running_var=None, mo
 
 
 def bn_backward(x, dy, yout, act, drop_scale, mode, period, mean, var, gamma, dist, dgamma, dbeta, want_dx=True,
-                dx=None, accumulate=False):
-    """BatchNorm (train mode) backward through the fused activation/dropout. Writes dgamma/dbeta
-    (local parts) and returns dx (global-batch exact under data parallelism)."""
+                dx=None, accumulate=False, batch_stats=True):
+    """BatchNorm backward through the fused activation/dropout. Writes dgamma/dbeta (local parts) and returns dx (global-batch
+    exact under data parallelism). batch_stats=False: the forward normalised with FIXED statistics (eval mode: mean / var are the
+    running buffers), so dx = gamma * rstd * g without the two batch-mean terms -- the same kernels with zero sums for dx."""
     _chk(x, torch.float32)
     rows, cols = x.shape
     ch = period if mode == 0 else cols
@@ -453,7 +454,9 @@ def bn_backward(x, dy, yout, act, drop_scale, mode, period, mean, var, gamma, di
     _lib.check(L.mla_bn_bwd_sums(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(yout), ld_y, act, float(drop_scale), rows, cols, mode,
                                  period, _p(mean), _p(var), BN_EPS, _p(_workspace(x.device)), _p(local), _lib.stream_ptr()))
     glob = local
-    if dist.bn_active:
+    if not batch_stats:
+        glob = torch.zeros_like(local)
+    elif dist.bn_active:
         glob = dist.all_reduce_sum(local.clone(), "syncbn_bwd")
     count = (rows // period * cols if mode == 0 else rows) * dist.bn_world
     if want_dx and dx is None:
