@@ -92,3 +92,40 @@ def test_parent_makes_no_gpu_call_before_spawning():
     assert main.index("launch_ranks(") < main.index("torch.cuda.")
     launch = src[src.index("def launch_ranks("):src.index("def dry_run(")]
     assert "torch.cuda" not in launch and "os.exec" not in launch
+
+
+def test_collective_summary_arithmetic():
+    """bench.collective_summary on a synthetic trace (no GPU): per-step bytes / ms, bus GB/s = 2 (N - 1) / N x bytes / time, SyncBN
+    counts, overlap_hidden_frac = 1 - exposed wait / all-reduce time."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Ev:
+        def __init__(self, t):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    class FakeDist:
+        trace = []
+
+        def describe(self):
+            return {"ranks": 8, "transport": "x"}
+
+    class FakeStep:
+        dist, exposed = FakeDist(), []
+
+    steps, world = 2, 8
+    for s in range(steps):
+        for tag, nbytes, ms in (("grad:mla", 3_244_304, 0.1), ("grad:fc0", 201_342_976, 2.0), ("syncbn_fwd", 160, 0.02), ("syncbn_bwd", 160, 0.03),
+                                ("loss", 4, 0.01), ("hits", 8, 0.01)):
+            FakeStep.dist.trace.append((tag, nbytes, Ev(0.0), Ev(ms)))
+        FakeStep.exposed.append((Ev(0.0), Ev(0.42)))
+    c = bench.collective_summary(FakeStep, steps, world)
+    assert c["ranks"] == 8 and c["allreduce_bytes_per_step"] == 3_244_304 + 201_342_976 and abs(c["allreduce_ms"] - 2.1) < 1e-12
+    assert abs(c["bus_GBps"] - 2 * 7 / 8 * (3_244_304 + 201_342_976) / 2.1e-3 / 1e9) < 1e-9
+    assert c["syncbn_allreduces_per_step"] == 2 and abs(c["syncbn_allreduce_ms"] - 0.05) < 1e-12 and c["syncbn_bytes_per_allreduce"] == 160
+    assert c["other_allreduces_per_step"] == 2 and set(c["gradient_messages_per_step"]) == {"mla", "fc0"}
+    assert abs(c["exposed_wait_ms"] - 0.42) < 1e-12 and abs(c["overlap_hidden_frac"] - (1 - 0.42 / 2.1)) < 1e-12
