@@ -75,6 +75,21 @@ def main():
         assert base[0] == coll[0] and base[1] == coll[1] and torch.equal(base[2], coll[2]), via
         print("nccl worker: %s transport ok, losses %s" % (via, coll[0]))
     os.environ["MLA_DIST_COLLECTIVE"] = "abi"
+    # a rank that cannot create its communicator through the C ABI: the ranks agree (MIN all-reduce) and ALL use torch's transport
+
+    d = ops.Dist(always=True)
+    assert d.via == "abi" and d.fallback is None and d.ranks_reported() == 1 and d.describe()["ranks"] == 1
+    d.close()
+    orig_init = ops.Dist._init_comm
+    ops.Dist._init_comm = lambda self, dist_mod: (_ for _ in ()).throw(RuntimeError("simulated: no ncclCommInitRank in this RCCL"))
+    try:
+        d = ops.Dist(always=True)
+    finally:
+        ops.Dist._init_comm = orig_init
+    assert d.via == "torch" and d.comm is None and "simulated" in d.fallback and d.describe()["fallback"] == d.fallback
+    t = torch.arange(7, dtype=torch.float32).cuda()
+    assert torch.equal(d.all_reduce_sum(t.clone()), t)
+    print("nccl worker: agreed fallback to torch's transport ok (%s)" % d.fallback)
     base = run_steps(mk, W, M, TR, False, True)
     for overlap in ("1", "0"):                     # bucketed reductions on the communication stream / one flat all-reduce at the end
         os.environ["MLA_DIST_OVERLAP"] = overlap

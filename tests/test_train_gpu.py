@@ -329,7 +329,7 @@ def test_rccl_branch_of_the_exchange_runs_on_one_rank():
                        stderr=subprocess.STDOUT, timeout=900)
     out = p.stdout.decode()
     assert p.returncode == 0 and "nccl worker ok" in out, out[-3000:]
-    assert "abi transport ok" in out and "torch transport ok" in out
+    assert "abi transport ok" in out and "torch transport ok" in out and "agreed fallback to torch's transport ok" in out
 
 
 def test_dropout_mask_stream_is_the_portable_generator(W):
