@@ -80,3 +80,30 @@ def test_train_mode_two_ranks_reports_the_collectives():
     d = run_bench("--gpus", "2", "--backend", "gloo", "--mode", "train", "--bags", "16", "--steps", "2", "--warmup", "1")
     assert d["n_gpus"] == 2 and d["config"]["global_batch_bags"] == 32 and d["collective"]["ranks"] == 2
     assert d["collective"]["syncbn_allreduces_per_step"] > 10 and d["collective"]["allreduce_bytes_per_step"] >= 4 * 811030
+
+
+def test_data_parallel_train_leg_over_rccl_on_one_rank():
+    """bench.dp_train_leg with backend nccl on a one-rank group, collectives forced on (tests/_bench_dp_worker.py): the production
+    transport end to end inside the bench leg -- what a box with one GPU can execute of BASELINE config 5."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(so.getsockname()[1])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_bench_dp_worker.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+    ts, co = d["train_step"], d["collective"]
+    for name in ("frozen_bf16", "frozen_bf16_per_shard_bn", "finetune_bf16"):
+        c = co[name]
+        assert c["ranks"] == 1 and c["backend"] == "nccl" and "mla_allreduce_flat" in c["transport"] and c["fallback"] is None
+        assert c["rccl_library_origin"] == "already loaded by the host"
+        assert c["allreduce_bytes_per_step"] >= 4 * ts[name]["trainable_floats"] and c["allreduce_ms"] > 0
+        assert c["other_allreduces_per_step"] == 2 and abs(ts[name]["loss_last"] - 2.3) < 0.3
+    assert co["frozen_bf16"]["syncbn_allreduces_per_step"] == 18 and co["frozen_bf16_per_shard_bn"]["syncbn_allreduces_per_step"] == 0
+    f = co["finetune_bf16"]
+    assert set(f["gradient_messages_per_step"]) == {"mla", "fc12", "fc0", "conv56", "conv14"} and 0.0 <= f["overlap_hidden_frac"] <= 1.0
+    assert f["gradient_messages_per_step"]["fc0"]["bytes"] == 4 * (12288 * 4096 + 4096)
