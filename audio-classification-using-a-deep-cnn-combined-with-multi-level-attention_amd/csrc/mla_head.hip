@@ -40,12 +40,20 @@ __device__ __forceinline__ float grad_through_act(float dy, float yout, int act,
 }
 
 // element functors of the per-channel reductions: (row, col, channel) -> the two summands
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
 struct StatsOp {                        // forward statistics: (x, x^2)
     const float* x; int64_t ldx;
     __device__ __forceinline__ void operator()(int64_t r, int c, int, double& a, double& b) const {
         const double v = x[r * ldx + c];
         a = v; b = v * v;
     }
+    // four consecutive columns with 16-byte loads, added to (a, b) in column order
+    __device__ __forceinline__ void quad(int64_t r, int c, int, double& a, double& b) const {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(x + r * ldx + c);
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) { const double d = v[e]; a += d; b += d * d; }
+    }
+    __device__ __forceinline__ bool vec_ok(int cols) const { return cols % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0; }
 };
 
 struct BwdOp {                          // backward: (g, g * xhat)
@@ -58,6 +66,22 @@ struct BwdOp {                          // backward: (g, g * xhat)
         const float xhat = (x[r * ldx + c] - mean[ch]) * (1.0f / sqrtf(var[ch] + eps));
         a = g; b = double(g) * xhat;
     }
+    __device__ __forceinline__ void quad(int64_t r, int c, int ch, double& a, double& b) const {
+        const f32x4_t d = *reinterpret_cast<const f32x4_t*>(dy + r * ld_dy + c);
+        const f32x4_t xv = *reinterpret_cast<const f32x4_t*>(x + r * ldx + c);
+        f32x4_t y = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (yout) y = *reinterpret_cast<const f32x4_t*>(yout + r * ld_y + c);
+        const float m = mean[ch], inv = 1.0f / sqrtf(var[ch] + eps);
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {
+            const float g = grad_through_act(d[e], y[e], act, drop_scale);
+            const float xhat = (xv[e] - m) * inv;
+            a += g; b += double(g) * xhat;
+        }
+    }
+    __device__ __forceinline__ bool vec_ok(int cols) const {
+        return cols % 4 == 0 && ldx % 4 == 0 && ld_dy % 4 == 0 && (!yout || ld_y % 4 == 0) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(yout) & 15) == 0;
+    }
 };
 
 // mode 0: channel = row % period; one wave per row, lanes stride the columns
@@ -65,6 +89,7 @@ template <typename Op>
 __global__ __launch_bounds__(256) void sums_rows_kernel(Op op, int64_t rows, int cols, int period, double* __restrict__ partial) {
     __shared__ double part[4][kMaxChannels][2];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool vec = op.vec_ok(cols);
     for (int i = threadIdx.x; i < 4 * kMaxChannels * 2; i += 256) (&part[0][0][0])[i] = 0.0;
     __syncthreads();
     const int64_t per_block = ((rows + gridDim.x - 1) / gridDim.x + period - 1) / period * period;
@@ -73,11 +98,15 @@ __global__ __launch_bounds__(256) void sums_rows_kernel(Op op, int64_t rows, int
     for (int64_t r = r0 + wave; r < r1; r += 4) {
         const int chan = int(r % period);
         double s = 0.0, ss = 0.0;
-        for (int c = lane; c < cols; c += 64) {
-            double a, b;
-            op(r, c, chan, a, b);
-            s += a;
-            ss += b;
+        if (vec) {                                           // 16-byte loads: a wave-instruction covers 1 KiB of the row
+            for (int c = 4 * lane; c < cols; c += 256) op.quad(r, c, chan, s, ss);
+        } else {
+            for (int c = lane; c < cols; c += 64) {
+                double a, b;
+                op(r, c, chan, a, b);
+                s += a;
+                ss += b;
+            }
         }
         s = wave_sum(s);
         ss = wave_sum(ss);

@@ -91,6 +91,29 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     if (g == 0 && c < cols) partial[int64_t(blockIdx.y) * cols + c] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
 }
 
+// the same with 16-byte loads: thread (row group g, column quad q) of block (x = 256-column tile, y = row chunk) adds the four
+// columns 4 q .. 4 q + 3 of rows g, g + 4, ... of the chunk; a wave reads 1 KiB of one row per instruction (the scalar form: 256 B)
+__global__ __launch_bounds__(256) void colsum_partial4_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols,
+                                                              double* __restrict__ partial) {
+    __shared__ double part[4][64][4];
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 4;
+    const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = int64_t(blockIdx.y) * per, r1 = r0 + per < rows ? r0 + per : rows;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (c < cols)
+        for (int64_t r = r0 + g; r < r1; r += 4) {
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(x + r * ldx + c);
+            s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+        }
+    part[g][lane][0] = s0; part[g][lane][1] = s1; part[g][lane][2] = s2; part[g][lane][3] = s3;
+    __syncthreads();
+    if (g == 0 && c < cols)
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)
+            partial[int64_t(blockIdx.y) * cols + c + e] = part[0][lane][e] + part[1][lane][e] + part[2][lane][e] + part[3][lane][e];
+}
+
 __global__ void colsum_finish_kernel(const double* __restrict__ partial, int chunks, int cols, float* __restrict__ out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cols) return;
@@ -211,10 +234,17 @@ extern "C" int mla_cross_entropy(const float* x, int64_t ldx, const int64_t* lab
 extern "C" int mla_col_sum(const float* x, int64_t ldx, int64_t rows, int64_t cols, void* workspace, float* out,
                            mla_stream_t stream) {
     MLA_REQUIRE(x && workspace && out && rows > 0 && cols > 0 && ldx >= cols, MLA_E_ARG, "bad col_sum arguments");
-    const int chunks = int(rows / 256 < 1 ? 1 : (rows / 256 > 64 ? 64 : rows / 256));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(unsigned((cols + 63) / 64), unsigned(chunks)), dim3(256), 0, s, x, ldx, rows,
-                       int(cols), static_cast<double*>(workspace));
+    int chunks;
+    if (cols % 4 == 0 && ldx % 4 == 0 && mla::aligned(x, 16)) {          // 16-byte loads, more row chunks (<= 64: the workspace)
+        chunks = int(rows / 64 < 1 ? 1 : (rows / 64 > 64 ? 64 : rows / 64));
+        hipLaunchKernelGGL(colsum_partial4_kernel, dim3(unsigned((cols + 255) / 256), unsigned(chunks)), dim3(256), 0, s, x, ldx, rows,
+                           int(cols), static_cast<double*>(workspace));
+    } else {
+        chunks = int(rows / 64 < 1 ? 1 : (rows / 64 > 64 ? 64 : rows / 64));       // narrow matrices (the attention modules' 10 columns): rows are the parallelism
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(unsigned((cols + 63) / 64), unsigned(chunks)), dim3(256), 0, s, x, ldx, rows,
+                           int(cols), static_cast<double*>(workspace));
+    }
     MLA_LAUNCH_OK("colsum partial");
     hipLaunchKernelGGL(colsum_finish_kernel, dim3(unsigned((cols + 255) / 256)), dim3(256), 0, s,
                        static_cast<const double*>(workspace), chunks, int(cols), out);

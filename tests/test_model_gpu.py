@@ -423,3 +423,21 @@ def test_ring_and_ksplit_gemms_do_not_depend_on_the_batch(ops, W, dtype):
             assert torch.equal(part, full[:rows]), (N, rows)
         shifted = ops.linear(aa[77:77 + 1020].contiguous(), ww, b, relu=True, out_dtype=torch.float32)
         assert torch.equal(shifted, full[77:77 + 1020]), N
+
+
+def test_col_sum_and_bn_sums_vectorised_and_scalar_paths(ops, W):
+    """mla_col_sum and the BatchNorm (sum, sum of squares) kernels take 16-byte loads when the column count, the row pitches and the
+    base pointers allow it and a scalar path otherwise: both against float64, on shapes that select each."""
+    for rows, cols in ((5120, 600), (777, 600), (64, 12), (300, 10), (1000, 601)):
+        x = torch.from_numpy(W.uniform(81, rows + cols, rows * cols, lo=-1.0, hi=2.0)).reshape(rows, cols).cuda()
+        out = torch.empty(cols, dtype=torch.float32, device="cuda")
+        ops.col_sum(x, out)
+        ref = x.double().sum(dim=0)
+        assert float((out.double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max()) + 1e-6, (rows, cols)
+    T = 10
+    for B, Fd in ((512, 600), (37, 600), (9, 10), (21, 601), (64, 128), (5, 12288)):
+        x = torch.from_numpy(W.uniform(82, B + Fd, B * T * Fd, lo=-2.0, hi=3.0)).reshape(B * T, Fd).cuda()
+        mean, var = ops.bn_stats(x, 0, T)
+        v3 = x.double().reshape(B, T, -1)
+        np.testing.assert_allclose(mean.cpu().numpy(), v3.mean(dim=(0, 2)).cpu().numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(var.cpu().numpy(), v3.var(dim=(0, 2), unbiased=False).cpu().numpy(), rtol=1e-5, atol=1e-7)
