@@ -354,6 +354,34 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
     out[m * ldo + n] = acc;
 }
 
+// The same for a SHORT reduction and a wide output (the input gradient of the attention modules' fcv: dz (rows, 10) . W (10, 600)):
+// the weights are staged once per block in LDS as [k][n], a thread produces four consecutive outputs of one row (16-byte store);
+// the K-long sum of every output runs in the same order as in linear_small_kernel (k ascending, one fma chain): same bits.
+__global__ __launch_bounds__(256) void linear_small_wide_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ w,
+                                                                int64_t ldw, const float* __restrict__ bias, float* __restrict__ out,
+                                                                int64_t ldo, int64_t M, int N, int K) {
+    extern __shared__ float s_w[];                        // [K][N]
+    for (int i = threadIdx.x; i < N * K; i += 256) {
+        const int n = i / K, kk = i - n * K;
+        s_w[kk * N + n] = w[int64_t(n) * ldw + kk];
+    }
+    __syncthreads();
+    const int quads = N / 4;
+    const int64_t total = M * quads;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < total; i += int64_t(gridDim.x) * 256) {
+        const int64_t m = i / quads;
+        const int n = int(i - m * quads) * 4;
+        float acc[4];
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) acc[e] = bias ? bias[n + e] : 0.f;
+        for (int kk = 0; kk < K; ++kk) {
+            const float av = a[m * lda + kk];
+            const f32x4_t wv = *reinterpret_cast<const f32x4_t*>(s_w + kk * N + n);
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) acc[e] = fmaf(av, wv[e], acc[e]);
+        }
+        *reinterpret_cast<f32x4_t*>(out + m * ldo + n) = f32x4_t{acc[0], acc[1], acc[2], acc[3]};
+    }
+}
+
 // out[m][n] = bias[n] + sum_k a[m][k] w[n][k] for a NARROW layer (N <= 16: the attention modules' fcv, model.py:230, 600 -> 10):
 // HBM-bound on reading `a` once. 16 lanes per row; lane l takes the float4 pieces l, l + 16, ... of the row (a wave-instruction
 // reads 4 x 256 contiguous bytes), the weights sit in LDS as [k/4][n] float4 so that the 16 lanes of a group read 16 different
@@ -556,6 +584,13 @@ extern "C" int mla_linear_small(const float* a, int64_t lda, const float* w, int
                                 int64_t ldo, int64_t M, int64_t N, int64_t K, mla_stream_t stream) {
     MLA_REQUIRE(a && w && out && M >= 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldo >= N, MLA_E_ARG, "bad linear_small arguments");
     if (M == 0) return MLA_OK;
+    if (N % 4 == 0 && N >= 64 && K <= 64 && N * K * 4 <= 48 * 1024 && ldo % 4 == 0 && mla::aligned(out, 16) && M * N >= (1 << 16)) {
+        const int64_t blocks = (M * (N / 4) + 255) / 256;
+        hipLaunchKernelGGL(linear_small_wide_kernel, dim3(unsigned(blocks < 1024 ? blocks : 1024)), dim3(256), size_t(N) * K * 4,
+                           static_cast<hipStream_t>(stream), a, lda, w, ldw, bias, out, ldo, M, int(N), int(K));
+        MLA_LAUNCH_OK("linear_small (wide)");
+        return MLA_OK;
+    }
     hipLaunchKernelGGL(linear_small_kernel, dim3(unsigned((M * N + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), a, lda, w, ldw, bias, out, ldo, M, int(N), int(K));
     MLA_LAUNCH_OK("linear_small");

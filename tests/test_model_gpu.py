@@ -441,3 +441,20 @@ def test_col_sum_and_bn_sums_vectorised_and_scalar_paths(ops, W):
         v3 = x.double().reshape(B, T, -1)
         np.testing.assert_allclose(mean.cpu().numpy(), v3.mean(dim=(0, 2)).cpu().numpy(), rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(var.cpu().numpy(), v3.var(dim=(0, 2), unbiased=False).cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_linear_small_wide_form_equals_the_plain_one(ops, W):
+    """mla_linear_small picks its wide-output kernel (weights in LDS, 16-byte stores) for large short-K problems -- the input gradient of
+    the attention modules' fcv, (rows, 10) x (10, 600) -> (rows, 600) -- and the one-thread-per-output kernel otherwise; the K-long
+    fma chain of an output is the same in both, so rows computed by either agree bit for bit, and both match float64."""
+    K, N = 10, 600
+    a = torch.from_numpy(W.uniform(83, 1, 5120 * K)).reshape(5120, K).cuda()
+    w = torch.from_numpy(W.uniform(83, 2, N * K)).reshape(N, K).cuda()
+    b = torch.from_numpy(W.uniform(83, 3, N)).cuda()
+    big = ops.linear_small(a, w, b)                               # 5120 x 600 outputs: wide kernel
+    small = ops.linear_small(a[:64].contiguous(), w, b)           # 64 x 600: plain kernel
+    assert torch.equal(big[:64], small)
+    ref = F.linear(a.double(), w.double(), b.double())
+    assert rel_err(big.cpu(), ref.cpu()) < 1e-6
+    nb = ops.linear_small(a, w, None)
+    assert rel_err(nb.cpu(), F.linear(a.double(), w.double()).cpu()) < 1e-6
