@@ -76,6 +76,7 @@ def lib():
         cd = ctypes.c_double
         L.mla_bn_stats_sums.argtypes = [vp, i64, i64, i64, ci, ci, vp, vp, vp]
         L.mla_bn_stats_finish.argtypes = [vp, ci, cd, vp, vp, vp, vp, cf, vp, vp]
+        L.mla_bn_stats_fused.argtypes = [vp, i64, i64, i64, ci, ci, vp, vp, vp, vp, vp, vp, cf, vp, vp]
         L.mla_bn_bwd_sums.argtypes = [vp, i64, vp, i64, vp, i64, ci, cf, i64, i64, ci, ci, vp, vp, cf, vp, vp, vp]
         L.mla_bn_bwd_apply.argtypes = [vp, i64, vp, i64, vp, i64, ci, cf, i64, i64, ci, ci, vp, vp, vp, cf, vp, vp, cd,
                                        vp, i64, ci, vp, vp, vp]

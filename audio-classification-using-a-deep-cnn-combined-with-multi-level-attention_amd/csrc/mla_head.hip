@@ -165,8 +165,39 @@ __global__ __launch_bounds__(64) void partial_reduce_kernel(const double* __rest
     if (lane == 0) { sums[2 * c] = s; sums[2 * c + 1] = ss; }
 }
 
+// partial_reduce_kernel and stats_finish_kernel in ONE launch for up to 16 channels (every BatchNorm of the head has 10): wave c
+// combines channel c's partials in the same fixed order, its lane 0 writes sums[c] and finishes mean / biased variance / running
+// statistics exactly as stats_finish_kernel does (same expressions: same bits). Used when no rank has to all-reduce the sums in between.
+struct FinishArgs {
+    double count; float* mean; float* var; float* run_mean; float* run_var; float momentum; int64_t* tracked;
+};
+__global__ __launch_bounds__(1024) void reduce_finish_kernel(const double* __restrict__ partial, int blocks, int channels,
+                                                             double* __restrict__ sums, FinishArgs f) {
+    const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x == 0 && f.tracked) *f.tracked += 1;
+    if (c >= channels) return;
+    double s = 0.0, ss = 0.0;
+    for (int b = lane; b < blocks; b += 64) { s += partial[(int64_t(b) * channels + c) * 2]; ss += partial[(int64_t(b) * channels + c) * 2 + 1]; }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if (lane != 0) return;
+    sums[2 * c] = s;
+    sums[2 * c + 1] = ss;
+    const double m = s / f.count;
+    double v = ss / f.count - m * m;
+    if (v < 0.0) v = 0.0;
+    f.mean[c] = float(m);
+    f.var[c] = float(v);
+    if (f.run_mean && f.momentum >= 0.f) {
+        const double unbiased = f.count > 1.0 ? v * f.count / (f.count - 1.0) : v;
+        f.run_mean[c] = float((1.0 - f.momentum) * f.run_mean[c] + f.momentum * m);
+        f.run_var[c] = float((1.0 - f.momentum) * f.run_var[c] + f.momentum * unbiased);
+    }
+}
+
 template <typename Op>
-int channel_sums(Op op, int64_t rows, int64_t cols, int mode, int period, void* workspace, double* sums, hipStream_t s) {
+int channel_sums(Op op, int64_t rows, int64_t cols, int mode, int period, void* workspace, double* sums, hipStream_t s,
+                 const FinishArgs* finish = nullptr) {
     double* partial = static_cast<double*>(workspace);
     const int channels = mode == 0 ? period : int(cols);
     int blocks;
@@ -179,6 +210,11 @@ int channel_sums(Op op, int64_t rows, int64_t cols, int mode, int period, void* 
         hipLaunchKernelGGL(sums_cols_kernel<Op>, dim3(blocks), dim3(256), 0, s, op, rows, int(cols), partial);
     }
     MLA_LAUNCH_OK("channel sums");
+    if (finish && channels <= 16) {
+        hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(64 * channels), 0, s, partial, blocks, channels, sums, *finish);
+        MLA_LAUNCH_OK("channel sums reduce + finish");
+        return 1;                                           // finished as well
+    }
     hipLaunchKernelGGL(partial_reduce_kernel, dim3(channels), dim3(64), 0, s, partial, blocks, channels, sums);
     MLA_LAUNCH_OK("channel sums reduce");
     return MLA_OK;
@@ -501,6 +537,25 @@ extern "C" int mla_bn_stats(const float* x, int64_t rows, int64_t cols, int64_t 
     const int channels = mode == 0 ? period : int(cols);
     const double count = mode == 0 ? double(rows / period) * double(cols) : double(rows);
     return mla_bn_stats_finish(sums, channels, count, mean, var_biased, running_mean, running_var, momentum, nullptr, stream);
+}
+
+// mla_bn_stats_sums + mla_bn_stats_finish in two launches instead of three (the reduction of the per-block partials and the finish
+// share one kernel for <= 16 channels): the single-process form of the train-mode statistics. sums_out: 2 * channels doubles, as
+// mla_bn_stats_sums writes them (a second BatchNorm fed by the same tensor finishes from them).
+extern "C" int mla_bn_stats_fused(const float* x, int64_t rows, int64_t cols, int64_t ldx, int mode, int period, void* workspace,
+                                  double* sums_out, float* mean, float* var_biased, float* running_mean, float* running_var,
+                                  float momentum, int64_t* num_batches_tracked, mla_stream_t stream) {
+    MLA_REQUIRE(x && workspace && sums_out && mean && var_biased && rows > 0 && cols > 0 && ldx >= cols, MLA_E_ARG, "bad bn_stats arguments");
+    MLA_REQUIRE(mode == 0 || mode == 1, MLA_E_ARG, "bn_stats mode %d", mode);
+    const int channels = mode == 0 ? period : int(cols);
+    MLA_REQUIRE(channels >= 1 && channels <= kMaxChannels, MLA_E_SHAPE, "bn_stats supports 1..%d channels (got %d)", kMaxChannels, channels);
+    MLA_REQUIRE(mode == 1 || rows % period == 0, MLA_E_SHAPE, "rows %lld not a multiple of period %d", (long long)rows, period);
+    const double count = mode == 0 ? double(rows / period) * double(cols) : double(rows);
+    const FinishArgs f{count, mean, var_biased, running_mean, running_var, momentum, num_batches_tracked};
+    const int rc = channel_sums(StatsOp{x, ldx}, rows, cols, mode, period, workspace, sums_out, static_cast<hipStream_t>(stream), &f);
+    if (rc == 1) return MLA_OK;
+    if (rc != MLA_OK) return rc;
+    return mla_bn_stats_finish(sums_out, channels, count, mean, var_biased, running_mean, running_var, momentum, num_batches_tracked, stream);
 }
 
 extern "C" int mla_bn_apply(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t cols, int mode,

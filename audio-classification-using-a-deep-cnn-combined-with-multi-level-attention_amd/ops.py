@@ -425,14 +425,17 @@ def bn_stats_sync(x, mode, period, dist, running_mean=None, running_var=None, mo
     ch = period if mode == 0 else cols
     sums = torch.empty(2 * ch, dtype=torch.float64, device=x.device)
     L = _lib.lib()
-    _lib.check(L.mla_bn_stats_sums(_p(x), rows, cols, x.stride(0), mode, period, _p(_workspace(x.device)), _p(sums), _lib.stream_ptr()))
-    if dist.bn_active:
-        dist.all_reduce_sum(sums, "syncbn_fwd")
-    count = (rows // period * cols if mode == 0 else rows) * dist.bn_world
     mean = torch.empty(ch, dtype=torch.float32, device=x.device)
     var = torch.empty(ch, dtype=torch.float32, device=x.device)
-    _lib.check(L.mla_bn_stats_finish(_p(sums), ch, float(count), _p(mean), _p(var), _p(running_mean), _p(running_var),
-                                     float(momentum), _p(tracked), _lib.stream_ptr()))
+    count = (rows // period * cols if mode == 0 else rows) * dist.bn_world
+    if dist.bn_active:
+        _lib.check(L.mla_bn_stats_sums(_p(x), rows, cols, x.stride(0), mode, period, _p(_workspace(x.device)), _p(sums), _lib.stream_ptr()))
+        dist.all_reduce_sum(sums, "syncbn_fwd")
+        _lib.check(L.mla_bn_stats_finish(_p(sums), ch, float(count), _p(mean), _p(var), _p(running_mean), _p(running_var),
+                                         float(momentum), _p(tracked), _lib.stream_ptr()))
+    else:               # nothing to exchange between the two stages: one launch fewer (same bits)
+        _lib.check(L.mla_bn_stats_fused(_p(x), rows, cols, x.stride(0), mode, period, _p(_workspace(x.device)), _p(sums), _p(mean), _p(var),
+                                        _p(running_mean), _p(running_var), float(momentum), _p(tracked), _lib.stream_ptr()))
     for rm, rv, mom, trk in also:
         scratch_m, scratch_v = torch.empty_like(mean), torch.empty_like(var)
         _lib.check(L.mla_bn_stats_finish(_p(sums), ch, float(count), _p(scratch_m), _p(scratch_v), _p(rm), _p(rv), float(mom), _p(trk),

@@ -228,6 +228,11 @@ int mla_bn_stats_sums(const float* x, int64_t rows, int64_t cols, int64_t ldx, i
 int mla_bn_stats_finish(const double* sums, int channels, double count, float* mean, float* var_biased,
                         float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked /* += 1, or NULL */,
                         mla_stream_t stream);
+/* Both stages for a single process (no all-reduce in between) in two launches instead of three; same results bit for bit.
+ * sums_out: the 2*channels doubles of stage 1 (for a second BatchNorm fed by the same tensor, model.py:237-238). */
+int mla_bn_stats_fused(const float* x, int64_t rows, int64_t cols, int64_t ldx, int mode, int period, void* workspace,
+                       double* sums_out, float* mean, float* var_biased, float* running_mean, float* running_var,
+                       float momentum, int64_t* num_batches_tracked, mla_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Training step: train.py:124-138 (zero_grad, forward, CrossEntropyLoss, backward, Adam)
